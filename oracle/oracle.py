@@ -1,0 +1,212 @@
+"""ctypes/numpy front end of oracle/smx_oracle.c (test infrastructure only)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libsmx_oracle.so")
+
+__all__ = [
+    "build", "lib", "Params", "gray", "xderiv", "cost_volume", "integral", "box_mean",
+    "guidance", "init_wta", "guided_filter", "detect_occlusion", "fill_occlusion",
+    "write_mat_u8", "stereo_pair", "pack_keys", "unpack_keys", "WTA_INIT_BITS",
+]
+
+WTA_INIT_BITS = 0x7F7F7F7F  # main.cu:112 memset(best, 9999999.0f) -> bytes 0x7F
+
+
+class Params(C.Structure):
+    _fields_ = [("r_w", C.c_double), ("g_w", C.c_double), ("b_w", C.c_double),
+                ("alpha", C.c_double), ("th_color", C.c_int), ("th_grad", C.c_int),
+                ("radius", C.c_int), ("eps", C.c_double), ("d_lr", C.c_int)]
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "smx_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_pack_key.restype = C.c_uint64
+        _lib.orc_pack_key.argtypes = [C.c_float, C.c_uint32]
+    return _lib
+
+
+def _params(p=None):
+    if p is not None:
+        return p
+    P = Params()
+    lib().orc_default_params(C.byref(P))
+    return P
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def gray(rgb, params=None):
+    rgb = _u8(rgb)
+    h, w, ch = rgb.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_gray(C.byref(_params(params)), _p(rgb, C.c_uint8), C.c_int64(h * w), C.c_int(ch),
+                   _p(out, C.c_uint8))
+    return out
+
+
+def xderiv(img):
+    img = _u8(img)
+    h, w = img.shape
+    out = np.empty((h, w), np.float32)
+    lib().orc_xderiv(_p(img, C.c_uint8), _p(out, C.c_float), w, h)
+    return out
+
+
+def cost_volume(i1, i2, size_d, dmin, params=None):
+    i1, i2 = _u8(i1), _u8(i2)
+    h, w1 = i1.shape
+    w2 = i2.shape[1]
+    out = np.empty((size_d, h, w1), np.float32)
+    lib().orc_cost_volume(C.byref(_params(params)), _p(i1, C.c_uint8), _p(i2, C.c_uint8),
+                          _p(out, C.c_float), w1, w2, h, size_d, dmin)
+    return out
+
+
+def integral(img):
+    img = _f32(img)
+    h, w = img.shape
+    out = np.empty((h, w), np.float32)
+    lib().orc_integral(_p(img, C.c_float), _p(out, C.c_float), w, h)
+    return out
+
+
+def box_mean(S, radius=9):
+    S = _f32(S)
+    h, w = S.shape
+    out = np.empty((h, w), np.float32)
+    lib().orc_box_mean(_p(S, C.c_float), _p(out, C.c_float), w, h, radius)
+    return out
+
+
+def guidance(I, params=None):
+    I = _u8(I)
+    h, w = I.shape
+    im = np.empty((h, w), np.float32)
+    mean = np.empty((h, w), np.float32)
+    var = np.empty((h, w), np.float32)
+    mean_u8 = np.empty((h, w), np.uint8)
+    lib().orc_guidance(C.byref(_params(params)), _p(I, C.c_uint8), _p(im, C.c_float),
+                       _p(mean, C.c_float), _p(var, C.c_float), _p(mean_u8, C.c_uint8), w, h)
+    return im, mean, var, mean_u8
+
+
+def init_wta(h, w):
+    best = np.full((h, w), WTA_INIT_BITS, np.uint32).view(np.float32)
+    dmap = np.zeros((h, w), np.float32)
+    return best, dmap
+
+
+def guided_filter(I, cost, dmin, best=None, dmap=None, s_begin=0, s_end=None, want_agg=False,
+                  params=None):
+    """Returns (best, dmap, mean_u8, agg or None); best/dmap are updated in place if given."""
+    I, cost = _u8(I), _f32(cost)
+    h, w = I.shape
+    size_d = cost.shape[0]
+    s_end = size_d if s_end is None else s_end
+    if best is None:
+        best, dmap = init_wta(h, w)
+    mean_u8 = np.empty((h, w), np.uint8)
+    agg = np.empty((s_end - s_begin, h, w), np.float32) if want_agg else None
+    lib().orc_guided_filter(C.byref(_params(params)), _p(I, C.c_uint8), _p(cost, C.c_float),
+                            _p(best, C.c_float), _p(dmap, C.c_float), _p(mean_u8, C.c_uint8),
+                            _p(agg, C.c_float), w, h, dmin, s_begin, s_end)
+    return best, dmap, mean_u8, agg
+
+
+def detect_occlusion(dL, dR, d_occlusion, params=None):
+    dL = _f32(dL).copy()
+    dR = _f32(dR)
+    h, w = dL.shape
+    lib().orc_detect_occlusion(C.byref(_params(params)), _p(dL, C.c_float), _p(dR, C.c_float),
+                               d_occlusion, w, h)
+    return dL
+
+
+def fill_occlusion(disp, vmin):
+    disp = _f32(disp).copy()
+    h, w = disp.shape
+    lib().orc_fill_occlusion(_p(disp, C.c_float), w, h, C.c_float(vmin))
+    return disp
+
+
+def write_mat_u8(mat):
+    mat = _f32(mat)
+    out = np.empty(mat.shape, np.uint8)
+    lib().orc_write_mat_u8(_p(mat, C.c_float), _p(out, C.c_uint8), C.c_int64(mat.size))
+    return out
+
+
+def stereo_pair(Il, Ir, size_d, dminl=None, dminr=0, want_cost=False, want_agg=False,
+                params=None):
+    """Whole main.cu:65-155 path on two gray u8 images. Returns a dict of arrays."""
+    Il, Ir = _u8(Il), _u8(Ir)
+    h, w = Il.shape
+    if dminl is None:
+        dminl = -(size_d - 1)
+    vol = (size_d, h, w)
+    r = {
+        "costl": np.empty(vol, np.float32) if want_cost else None,
+        "costr": np.empty(vol, np.float32) if want_cost else None,
+        "aggl": np.empty(vol, np.float32) if want_agg else None,
+        "aggr": np.empty(vol, np.float32) if want_agg else None,
+        "bestl": np.empty((h, w), np.float32), "bestr": np.empty((h, w), np.float32),
+        "dmapl": np.empty((h, w), np.float32), "dmapr": np.empty((h, w), np.float32),
+        "meanl": np.empty((h, w), np.uint8), "meanr": np.empty((h, w), np.uint8),
+        "occlusion": np.empty((h, w), np.float32), "filled": np.empty((h, w), np.float32),
+    }
+    f, u = C.c_float, C.c_uint8
+    lib().orc_stereo_pair(C.byref(_params(params)), _p(Il, u), _p(Ir, u), w, h, size_d, dminl, dminr,
+                          _p(r["costl"], f), _p(r["costr"], f), _p(r["aggl"], f), _p(r["aggr"], f),
+                          _p(r["bestl"], f), _p(r["bestr"], f), _p(r["dmapl"], f), _p(r["dmapr"], f),
+                          _p(r["meanl"], u), _p(r["meanr"], u), _p(r["occlusion"], f),
+                          _p(r["filled"], f))
+    return r
+
+
+def pack_keys(best, slices):
+    """numpy restatement of orc_pack_key over arrays (checked against the C one in tests)."""
+    b = _f32(best).copy()
+    b[b == 0.0] = 0.0
+    u = b.view(np.uint32)
+    neg = (u & np.uint32(0x80000000)) != 0
+    o = np.where(neg, ~u, u | np.uint32(0x80000000)).astype(np.uint64)
+    lo = (np.uint64(0xFFFFFFFF) - np.asarray(slices).astype(np.uint64))
+    return (o << np.uint64(32)) | lo
+
+
+def unpack_keys(keys):
+    keys = np.asarray(keys, dtype=np.uint64)
+    u = (keys >> np.uint64(32)).astype(np.uint32)
+    pos = (u & np.uint32(0x80000000)) != 0
+    bits = np.where(pos, u & np.uint32(0x7FFFFFFF), ~u).astype(np.uint32)
+    best = bits.view(np.float32)
+    slices = (np.uint64(0xFFFFFFFF) - (keys & np.uint64(0xFFFFFFFF))).astype(np.int64)
+    return best, slices
