@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Benchmark of the stereo-pair -> disparity-map path (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one synthetic 1242x375 stereo pair at D=192 through the whole path: fused cost build,
+guided-filter aggregation + running WTA of both views, (N > 1: one RCCL MIN all-reduce of the packed
+keys, the disparity slices being sharded across ranks), decode, LR check, filling.  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+roofline: the aggregation operator (smx_dev_aggregate_wta) against HBM: algorithmic bytes are
+8 B per (pixel, disparity) cell of one volume (read raw cost 4 B + write/consume aggregated cost
+4 B) x the cells one call processes, divided by the call's average device time,
+measured live with HIP events on the launch stream.
+cpu_baseline: the CPU oracle (port of the reference kernels, 1 thread) timed on this box's host
+cores on the same pair -- a reported baseline, not the target.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+ALGO_BYTES_PER_CELL = 8.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="kitti", choices=["tsukuba", "kitti", "motorcycle", "4k"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slices-in-flight", type=int, default=None)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import stereo_matching_cuda_amd as smx
+    from stereo_matching_cuda_amd import synth
+    from stereo_matching_cuda_amd.sharded import ShardedPair, shard_range
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    smx.lib()  # fail loudly if the HIP extension is missing
+    w, h, D = synth.SHAPES[args.workload]
+    seed = synth.SEEDS.get(args.workload, 1)
+    Il, Ir = synth.gen_pair(w, h, D, seed)
+    dl = torch.from_numpy(Il).to(device)
+    dr = torch.from_numpy(Ir).to(device)
+
+    sp = ShardedPair(w, h, D, rank=rank, world=world, device=device,
+                     slices_in_flight=args.slices_in_flight)
+    pipe = sp.pipe
+    local_slices = pipe.s_end - pipe.s_begin
+
+    def step(events=None):
+        pipe.init_keys()
+        for view, (g, o) in enumerate(((dl, dr), (dr, dl))):
+            if events is not None:
+                e0 = torch.cuda.Event(enable_timing=True)
+                e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+            pipe.aggregate_view(view, g, o)
+            if events is not None:
+                e1.record()
+                events.append((e0, e1))
+        if world > 1:
+            from stereo_matching_cuda_amd.sharded import allreduce_min_keys_
+            allreduce_min_keys_(pipe.keys)
+        pipe.finish()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    events = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(events)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    agg_ms = [a.elapsed_time(b) for a, b in events]
+    agg_avg_s = (sum(agg_ms) / max(1, len(agg_ms))) * 1e-3
+    cells_per_call = float(w) * h * local_slices
+    achieved = ALGO_BYTES_PER_CELL * cells_per_call / agg_avg_s / 1e9 if agg_avg_s > 0 else 0.0
+
+    result = {
+        "metric": "disparity MPix/s (stereo pair -> L+R disparity + occlusion-filled map)",
+        "value": (w * h * args.steps) / dt / 1e6,
+        "unit": "MPix/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload} {w}x{h} D={D} seeded synthetic pair (seed {seed})",
+                   "width": w, "height": h, "disparities": D,
+                   "sharding": f"disparity slices / {world} ranks" if world > 1 else "none",
+                   "slices_in_flight": pipe.slices_in_flight, "library": smx.lib().smx_version().decode()},
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "guided-filter aggregation + WTA (smx_dev_aggregate_wta, one view)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "avg_launch_ms": agg_avg_s * 1e3,
+            "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * cells_per_call,
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        oracle.build()
+        try:
+            os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+        except (AttributeError, OSError):
+            pass
+        # bounded sample: the full pair when it takes <~30 s at one thread, else a slice subset
+        cells = float(w) * h * D * 2
+        sample_d = D if cells <= 4e8 else max(4, int(4e8 / (2.0 * w * h)))
+        t0 = time.perf_counter()
+        oracle.stereo_pair(Il, Ir, sample_d)
+        cdt = time.perf_counter() - t0
+        scale = D / sample_d
+        result["cpu_baseline"] = {
+            "value": (w * h) / (cdt * scale) / 1e6,
+            "unit": "MPix/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": (f"oracle/smx_oracle.c (gcc -O2 -ffp-contract=off), 1 thread, same pair, "
+                       f"{sample_d} of {D} disparities per view"
+                       + ("" if sample_d == D else f", time scaled x{scale:.2f} (linear in D)")
+                       + f", {cdt:.1f} s"),
+        }
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

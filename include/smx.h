@@ -1,0 +1,176 @@
+/*
+ * smx.h -- C-ABI of the MI355X (gfx950) stereo-pair -> disparity-map library
+ *          (libsmx_hip.so, built from stereo_matching_cuda_amd/csrc/).
+ *
+ * This is the drop-in boundary for the one hot path of hamza1030/stereo_matching_cuda:
+ *   gray -> cost volume -> guided-filter aggregation + winner-take-all -> LR check -> fill.
+ * Every entry point cites the reference host function it replaces (paths relative to the
+ * reference's stereo_matching_cuda/ directory).  Plain pointers and sizes only.
+ *
+ * Two families:
+ *   smx_<stage>()      host pointers in / host pointers out, synchronous -- exactly the
+ *                      calling convention of the reference's per-stage wrappers, so the
+ *                      reference-signature C++ functions in stereo_matching_cuda_amd/host/
+ *                      (costVolume.cuh, guidedFilter.cuh, ...) are one-line forwards.
+ *   smx_dev_<stage>()  device pointers, asynchronous on a caller-supplied hipStream_t
+ *                      (passed as void*), caller-supplied workspace; no allocation, no
+ *                      synchronisation inside -> capturable in a hipGraph.  Used by the
+ *                      fused pair path, the benchmark and the multi-GPU (D-sharded) driver.
+ *
+ * All functions return 0 on success or a negative code (SMX_E_*); smx_last_error() gives
+ * the message of the last failure on the calling thread.  There is no CPU fallback: without
+ * a HIP device every compute entry point fails with SMX_E_HIP.
+ *
+ * Layouts (reference: costVolume.cu:178, guidedFilter.cu:173,198): images row-major [y][x];
+ * volumes [z][y][x] with plane stride w*h; disparity maps are float arrays holding integer
+ * labels (dmin + slice index).
+ */
+#ifndef SMX_H
+#define SMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+#define SMX_OK 0
+#define SMX_E_ARG (-1)  /* bad argument (null pointer, non-positive size, ...) */
+#define SMX_E_HIP (-2)  /* HIP runtime error or no device */
+#define SMX_E_WS (-3)   /* workspace too small */
+
+/* Tunables of the reference (SystemIncludes.h:7-24), runtime instead of macros. */
+typedef struct smx_params {
+    double r_w, g_w, b_w; /* R_W 0.299, G_W 0.587, B_W 0.0721 (sic)  SystemIncludes.h:7-9 */
+    double alpha;         /* ALPHA 0.9                                :10 */
+    int th_color;         /* TH_color 7                               :14 */
+    int th_grad;          /* TH_grad 2                                :13 */
+    int radius;           /* RADIUS 9                                 :21 */
+    double eps;           /* EPS 6.5025                               :23 */
+    int d_lr;             /* D_LR 0                                   :24 */
+} smx_params;
+
+void smx_default_params(smx_params* p);
+const char* smx_last_error(void);
+const char* smx_version(void);
+/* Number of visible HIP devices (0 if none / runtime unusable). Never fails. */
+int smx_device_count(void);
+
+/* ------------------------------------------------------------------------------------
+ * Host-pointer stage API (reference L2 wrappers)
+ * ---------------------------------------------------------------------------------- */
+
+/* rgb_to_grayscale.cuh:7  unsigned char* rgb_to_grayscale(h_rgb, n, channels, compare)
+ * gray[k] = (uchar)(R_W*r + G_W*g + B_W*b) in double.  h_gray: caller-allocated, n bytes. */
+int smx_rgb_to_grayscale(const smx_params* p, const uint8_t* h_rgb, int64_t n, int channels,
+                         uint8_t* h_gray);
+
+/* costVolume.cuh:7  void compute_cost(i1, i2, cost, w1, w2, h1, h2, dmin, compare)
+ * size_d is explicit here (the reference derives it from macros, costVolume.cu:5).
+ * cost: size_d*w1*h1 floats, [z][y][x], label of slice z = dmin + z. */
+int smx_compute_cost(const smx_params* p, const uint8_t* i1, const uint8_t* i2, float* cost,
+                     int w1, int w2, int h1, int h2, int size_d, int dmin);
+
+/* integral.cuh:3  void integral(float* image, float* integral, int width, int height) */
+int smx_integral(const float* image, float* integral, int width, int height);
+
+/* guidedFilter.cuh:7  void compute_guided_filter(i, cost, filter_cost, disp_map, mean, w, h,
+ *                                                size_d, dmin, compare)
+ * filter_cost / disp_map are IN/OUT exactly as in the reference (main.cu:112-118 presets them
+ * to 0x7F7F7F7F / 0): a pixel is updated iff filter_cost >= min_z q[z].  mean (u8, optional)
+ * receives trunc(mean_I).  agg (optional, size_d*w*h floats) receives the aggregated volume q,
+ * which the reference never materialises (guidedFilter.cu:233). */
+int smx_compute_guided_filter(const smx_params* p, const uint8_t* i, const float* cost,
+                              float* filter_cost, float* disp_map, uint8_t* mean, float* agg,
+                              int w, int h, int size_d, int dmin);
+
+/* occlusion.cuh:8  void detect_occlusion(dL, dR, dOcclusion, dmapl, dmapr, w, h)
+ * (the two u8 arguments of the reference are dead: occlusion.cu:51-52). dL is in/out. */
+int smx_detect_occlusion(const smx_params* p, float* disparityLeft, const float* disparityRight,
+                         int dOcclusion, int w, int h);
+
+/* occlusion.cuh:14  void fill_occlusion(float* disparity, w, h, vMin) ; in place. */
+int smx_fill_occlusion(float* disparity, int w, int h, float vMin);
+
+/* main.cu:65-155 as one call on two gray images (device-resident between stages).
+ * Left volume labels dminl .. dminl+size_d-1, right volume dminr .. dminr+size_d-1
+ * (main.cu:79-82).  Any output pointer may be NULL.  occlusion uses dOcclusion = dminl-100
+ * (main.cu:149) and filling uses vMin = dminl (main.cu:154). */
+typedef struct smx_pair_out {
+    float* best_l; float* best_r;   /* n floats each: WTA cost (main.cu best_costl/r)      */
+    float* dmap_l; float* dmap_r;   /* n floats each: labels                                */
+    uint8_t* mean_l; uint8_t* mean_r;
+    float* occlusion;               /* left map after LR check                              */
+    float* filled;                  /* after scan-line filling                              */
+    float* cost_l; float* cost_r;   /* size_d*n floats each, raw cost volumes (optional)    */
+    float* agg_l; float* agg_r;     /* size_d*n floats each, aggregated volumes (optional)  */
+} smx_pair_out;
+
+int smx_stereo_pair(const smx_params* p, const uint8_t* gray_l, const uint8_t* gray_r, int w,
+                    int h, int size_d, int dminl, int dminr, const smx_pair_out* out);
+
+/* ------------------------------------------------------------------------------------
+ * Device-pointer API (async on `stream`, no allocation inside)
+ * ---------------------------------------------------------------------------------- */
+
+int smx_dev_rgb_to_grayscale(const smx_params* p, const uint8_t* d_rgb, int64_t n, int channels,
+                             uint8_t* d_gray, void* stream);
+
+/* Slices [s_begin, s_end) of the volume whose slice z has label dmin+z are written to
+ * d_cost[(z - s_begin) * w1*h]. */
+int smx_dev_cost_volume(const smx_params* p, const uint8_t* d_i1, const uint8_t* d_i2,
+                        float* d_cost, int w1, int w2, int h, int dmin, int s_begin, int s_end,
+                        void* stream);
+
+/* nplanes independent w*h planes, in place allowed (d_in == d_out). */
+int smx_dev_integral(const float* d_in, float* d_out, int w, int h, int nplanes, void* stream);
+
+/* Bytes of workspace smx_dev_aggregate_wta needs for `nslices` slices in flight. */
+size_t smx_agg_workspace_bytes(int w, int h, int nslices);
+
+/* Guided-filter aggregation + running winner-take-all over slices [s_begin, s_end) of ONE
+ * volume (reference: guidedFilter.cu:171-238 incl. dispSelectOnGPU :403-411).
+ *   d_guide  : guidance image I (u8, w*h) -- the image the volume belongs to
+ *   d_other  : the other view; used to build cost slices on the fly when d_cost == NULL
+ *              (costVolume.cu:163-190 fused in).  May be NULL when d_cost is given.
+ *   d_cost   : optional materialised cost slices, slice s at d_cost[(s - s_begin)*w*h]
+ *   d_keys   : n packed u64 WTA keys, IN/OUT: key = ord(cost)<<32 | (0xFFFFFFFF - slice);
+ *              initialise with smx_dev_init_keys; min-combine across shards (all-reduce MIN)
+ *   d_mean_u8: optional u8 mean image out (guidedFilter.cu:87,122)
+ *   d_agg    : optional aggregated slices out, slice s at d_agg[(s - s_begin)*w*h]
+ * Slices are processed in chunks that fit the workspace (>= smx_agg_workspace_bytes(w,h,1)). */
+int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uint8_t* d_other,
+                          const float* d_cost, int w, int h, int dmin, int s_begin, int s_end,
+                          uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
+                          size_t workspace_bytes, void* stream);
+
+/* winner_take_all.cuh (live WTA = dispSelectOnGPU, guidedFilter.cu:403-411), packed form. */
+int smx_dev_init_keys(uint64_t* d_keys, int64_t n, void* stream);
+/* Fold keys into best/dmap with the reference's rule: if (best >= q) { dmap = dmin + slice;
+ * best = q; }.  best/dmap are IN/OUT (use smx_dev_init_wta for the reference's presets). */
+int smx_dev_apply_keys(const uint64_t* d_keys, int64_t n, int dmin, float* d_best, float* d_dmap,
+                       void* stream);
+/* main.cu:112-118: best <- 0x7F7F7F7F bit pattern, dmap <- 0. */
+int smx_dev_init_wta(float* d_best, float* d_dmap, int64_t n, void* stream);
+
+int smx_dev_detect_occlusion(const smx_params* p, float* d_dL, const float* d_dR, int dOcclusion,
+                             int w, int h, void* stream);
+int smx_dev_fill_occlusion(float* d_disp, int w, int h, float vMin, void* stream);
+
+/* Host-side helpers for the packed key (same encoding as the kernels). */
+uint64_t smx_pack_key(float cost, uint32_t slice);
+void smx_unpack_key(uint64_t key, float* cost, uint32_t* slice);
+
+/* Cumulative device time (ms) of the aggregation kernels launched by the most recent
+ * smx_dev_aggregate_wta call on this thread when timing was enabled with
+ * smx_set_timing(1); measured with hipEvents on the caller's stream (synchronises). */
+int smx_set_timing(int enable);
+int smx_last_agg_ms(float* ms, int* launches);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMX_H */

@@ -1,0 +1,404 @@
+// smx_capi.hip -- the C-ABI of include/smx.h: argument checks, workspace carving, stage
+// orchestration, and the host-pointer wrappers that mirror the reference's per-stage functions.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "smx_launch.h"
+
+namespace smx {
+
+static thread_local std::string g_err;
+static thread_local bool g_timing = false;
+static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+static thread_local bool g_ev_valid = false;
+static thread_local int g_launches = 0;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+// RAII device allocation for the host-pointer wrappers.
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <class T> T* as() { return (T*)p; }
+};
+
+constexpr size_t WS_ALIGN = 256;
+
+static size_t plane_bytes(int w, int h) { return align_up((size_t)w * h * sizeof(float), WS_ALIGN); }
+
+}  // namespace smx
+
+using namespace smx;
+
+extern "C" {
+
+void smx_default_params(smx_params* p) {
+    if (!p) return;
+    p->r_w = 0.299; p->g_w = 0.587; p->b_w = 0.0721;
+    p->alpha = 0.9; p->th_color = 7; p->th_grad = 2;
+    p->radius = 9; p->eps = 6.5025; p->d_lr = 0;
+}
+
+const char* smx_last_error(void) { return g_err.c_str(); }
+
+const char* smx_version(void) { return "smx-hip gfx950 0.1 (v1 dataflow)"; }
+
+int smx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+uint64_t smx_pack_key(float cost, uint32_t slice) { return pack_key(cost, slice); }
+void smx_unpack_key(uint64_t key, float* cost, uint32_t* slice) {
+    float c; uint32_t s;
+    unpack_key(key, &c, &s);
+    if (cost) *cost = c;
+    if (slice) *slice = s;
+}
+
+int smx_set_timing(int enable) {
+    g_timing = enable != 0;
+    if (g_timing && !g_ev0) {
+        SMX_HIP(hipEventCreate(&g_ev0));
+        SMX_HIP(hipEventCreate(&g_ev1));
+    }
+    g_ev_valid = false;
+    return SMX_OK;
+}
+
+int smx_last_agg_ms(float* ms, int* launches) {
+    if (!g_ev_valid) return fail(SMX_E_ARG, "smx_last_agg_ms: no timed aggregation recorded");
+    SMX_HIP(hipEventSynchronize(g_ev1));
+    float t = 0;
+    SMX_HIP(hipEventElapsedTime(&t, g_ev0, g_ev1));
+    if (ms) *ms = t;
+    if (launches) *launches = g_launches;
+    return SMX_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * device-pointer API
+ * ---------------------------------------------------------------------------------------- */
+
+int smx_dev_rgb_to_grayscale(const smx_params* p, const uint8_t* d_rgb, int64_t n, int channels,
+                             uint8_t* d_gray, void* stream) {
+    SMX_ARG(p && d_rgb && d_gray && n > 0 && channels >= 3);
+    return launch_gray(p, d_rgb, n, channels, d_gray, (hipStream_t)stream);
+}
+
+int smx_dev_cost_volume(const smx_params* p, const uint8_t* d_i1, const uint8_t* d_i2, float* d_cost,
+                        int w1, int w2, int h, int dmin, int s_begin, int s_end, void* stream) {
+    SMX_ARG(p && d_i1 && d_i2 && d_cost);
+    SMX_ARG(w1 >= 2 && h >= 1 && w1 == w2 && s_begin >= 0 && s_end >= s_begin);
+    return launch_cost(p, d_i1, d_i2, d_cost, w1, h, dmin + s_begin, s_end - s_begin,
+                       (hipStream_t)stream);
+}
+
+int smx_dev_integral(const float* d_in, float* d_out, int w, int h, int nplanes, void* stream) {
+    SMX_ARG(d_in && d_out && w >= 1 && h >= 1 && nplanes >= 0);
+    return launch_integral(0, d_in, nullptr, d_out, nullptr, w, h, nplanes, (hipStream_t)stream);
+}
+
+size_t smx_agg_workspace_bytes(int w, int h, int nslices) {
+    if (w < 1 || h < 1 || nslices < 1) return 0;
+    // guidance: im, mean_im, cinv, S_im, S_sq ; per slice in flight: cost, T0, T1, A, B
+    return plane_bytes(w, h) * (5 + 5 * (size_t)nslices) + WS_ALIGN;
+}
+
+int smx_dev_init_keys(uint64_t* d_keys, int64_t n, void* stream) {
+    SMX_ARG(d_keys && n > 0);
+    return launch_init_keys(d_keys, n, (hipStream_t)stream);
+}
+
+int smx_dev_init_wta(float* d_best, float* d_dmap, int64_t n, void* stream) {
+    SMX_ARG(d_best && d_dmap && n > 0);
+    return launch_init_wta(d_best, d_dmap, n, (hipStream_t)stream);
+}
+
+int smx_dev_apply_keys(const uint64_t* d_keys, int64_t n, int dmin, float* d_best, float* d_dmap,
+                       void* stream) {
+    SMX_ARG(d_keys && d_best && d_dmap && n > 0);
+    return launch_apply_keys(d_keys, n, dmin, d_best, d_dmap, (hipStream_t)stream);
+}
+
+int smx_dev_detect_occlusion(const smx_params* p, float* d_dL, const float* d_dR, int dOcclusion,
+                             int w, int h, void* stream) {
+    SMX_ARG(p && d_dL && d_dR && w >= 1 && h >= 1);
+    return launch_detect_occlusion(p, d_dL, d_dR, dOcclusion, w, h, (hipStream_t)stream);
+}
+
+int smx_dev_fill_occlusion(float* d_disp, int w, int h, float vMin, void* stream) {
+    SMX_ARG(d_disp && w >= 1 && h >= 1);
+    return launch_fill_occlusion(d_disp, w, h, vMin, (hipStream_t)stream);
+}
+
+int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uint8_t* d_other,
+                          const float* d_cost, int w, int h, int dmin, int s_begin, int s_end,
+                          uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
+                          size_t workspace_bytes, void* stream) {
+    SMX_ARG(p && d_guide && d_keys && d_workspace);
+    SMX_ARG(d_cost || d_other);
+    SMX_ARG(w >= 2 && h >= 1 && s_begin >= 0 && s_end >= s_begin && p->radius >= 0);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t pb = plane_bytes(w, h);
+    const int64_t n = (int64_t)w * h;
+    char* base = (char*)align_up((size_t)d_workspace, WS_ALIGN);
+    size_t avail = workspace_bytes - (size_t)(base - (char*)d_workspace);
+    if (workspace_bytes < WS_ALIGN || avail < pb * 10)
+        return fail(SMX_E_WS, "smx_dev_aggregate_wta: workspace %zu B < %zu B needed for one slice",
+                    workspace_bytes, smx_agg_workspace_bytes(w, h, 1));
+    const int per_slice = d_cost ? 4 : 5;
+    const int total = s_end - s_begin;
+    const size_t slice_b = (size_t)n * sizeof(float);
+    // largest chunk c with 5 guidance planes + per_slice volumes of c slices inside `avail`
+    size_t c_fit = (avail - 5 * pb) / per_slice / slice_b;
+    while (c_fit > 1 && 5 * pb + per_slice * align_up(c_fit * slice_b, WS_ALIGN) > avail) --c_fit;
+    int chunk = c_fit > (size_t)total ? total : (int)c_fit;
+    if (chunk < 1) chunk = 1;
+    float* im = (float*)(base + 0 * pb);
+    float* mean_im = (float*)(base + 1 * pb);
+    float* cinv = (float*)(base + 2 * pb);
+    float* g0 = (float*)(base + 3 * pb);
+    float* g1 = (float*)(base + 4 * pb);
+    char* cb = base + 5 * pb;
+    // chunk volumes are packed with plane stride n floats (kernels index planes as z*n)
+    const size_t vol = align_up((size_t)chunk * slice_b, WS_ALIGN);
+    float* T0 = (float*)(cb + 0 * vol);
+    float* T1 = (float*)(cb + 1 * vol);
+    float* A = (float*)(cb + 2 * vol);
+    float* B = (float*)(cb + 3 * vol);
+    float* C = d_cost ? nullptr : (float*)(cb + 4 * vol);
+
+    int rc;
+    g_launches = 0;
+    if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
+    // guidance statistics (guidedFilter.cu:58-123)
+    if ((rc = launch_guid_prep(d_guide, im, g1, n, st))) return rc;
+    if ((rc = launch_integral(2, im, g1, g0, g1, w, h, 1, st))) return rc;
+    if ((rc = launch_guid_finish(p, g0, g1, mean_im, cinv, d_mean_u8, w, h, st))) return rc;
+    g_launches += 4;
+    // slice loop (guidedFilter.cu:171-238), `chunk` slices per pass
+    for (int s0 = s_begin; s0 < s_end; s0 += chunk) {
+        const int cnt = (s_end - s0) < chunk ? (s_end - s0) : chunk;
+        const float* cost = d_cost ? d_cost + (int64_t)(s0 - s_begin) * n : C;
+        if (!d_cost) {
+            if ((rc = launch_cost(p, d_guide, d_other, C, w, h, dmin + s0, cnt, st))) return rc;
+            ++g_launches;
+        }
+        if ((rc = launch_integral(1, cost, im, T0, T1, w, h, cnt, st))) return rc;
+        if ((rc = launch_ab(p, T0, T1, mean_im, cinv, A, B, w, h, cnt, st))) return rc;
+        if ((rc = launch_integral(2, A, B, A, B, w, h, cnt, st))) return rc;
+        float* agg = d_agg ? d_agg + (int64_t)(s0 - s_begin) * n : nullptr;
+        if ((rc = launch_q_wta(p, A, B, im, d_keys, agg, w, h, cnt, s0, st))) return rc;
+        g_launches += 6;
+    }
+    if (g_timing) {
+        SMX_HIP(hipEventRecord(g_ev1, st));
+        g_ev_valid = true;
+    }
+    return SMX_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * host-pointer stage API (reference L2 wrappers: allocate, upload, run, download, free)
+ * ---------------------------------------------------------------------------------------- */
+
+int smx_rgb_to_grayscale(const smx_params* p, const uint8_t* h_rgb, int64_t n, int channels,
+                         uint8_t* h_gray) {
+    SMX_ARG(p && h_rgb && h_gray && n > 0 && channels >= 3);
+    DevBuf rgb, gray;
+    SMX_HIP(rgb.alloc((size_t)n * channels));
+    SMX_HIP(gray.alloc((size_t)n));
+    SMX_HIP(hipMemcpy(rgb.p, h_rgb, (size_t)n * channels, hipMemcpyHostToDevice));
+    int rc = smx_dev_rgb_to_grayscale(p, rgb.as<uint8_t>(), n, channels, gray.as<uint8_t>(), nullptr);
+    if (rc) return rc;
+    SMX_HIP(hipDeviceSynchronize());
+    SMX_HIP(hipMemcpy(h_gray, gray.p, (size_t)n, hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+int smx_compute_cost(const smx_params* p, const uint8_t* i1, const uint8_t* i2, float* cost, int w1,
+                     int w2, int h1, int h2, int size_d, int dmin) {
+    SMX_ARG(p && i1 && i2 && cost && size_d >= 1);
+    SMX_ARG(w1 >= 2 && w1 == w2 && h1 >= 1 && h1 == h2);
+    const size_t n = (size_t)w1 * h1;
+    DevBuf d1, d2, dc;
+    SMX_HIP(d1.alloc(n));
+    SMX_HIP(d2.alloc(n));
+    SMX_HIP(dc.alloc(n * size_d * sizeof(float)));
+    SMX_HIP(hipMemcpy(d1.p, i1, n, hipMemcpyHostToDevice));
+    SMX_HIP(hipMemcpy(d2.p, i2, n, hipMemcpyHostToDevice));
+    int rc = smx_dev_cost_volume(p, d1.as<uint8_t>(), d2.as<uint8_t>(), dc.as<float>(), w1, w2, h1,
+                                 dmin, 0, size_d, nullptr);
+    if (rc) return rc;
+    SMX_HIP(hipDeviceSynchronize());
+    SMX_HIP(hipMemcpy(cost, dc.p, n * size_d * sizeof(float), hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+int smx_integral(const float* image, float* integral, int width, int height) {
+    SMX_ARG(image && integral && width >= 1 && height >= 1);
+    const size_t bytes = (size_t)width * height * sizeof(float);
+    DevBuf d;
+    SMX_HIP(d.alloc(bytes));
+    SMX_HIP(hipMemcpy(d.p, image, bytes, hipMemcpyHostToDevice));
+    int rc = smx_dev_integral(d.as<float>(), d.as<float>(), width, height, 1, nullptr);
+    if (rc) return rc;
+    SMX_HIP(hipDeviceSynchronize());
+    SMX_HIP(hipMemcpy(integral, d.p, bytes, hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+static size_t pick_ws_bytes(int w, int h, int size_d) {
+    // keep at most ~2 GiB of slices in flight for the host-pointer wrappers
+    const size_t one = smx_agg_workspace_bytes(w, h, 1);
+    const size_t all = smx_agg_workspace_bytes(w, h, size_d);
+    const size_t cap = (size_t)2 << 30;
+    if (all <= cap) return all;
+    return one > cap ? one : cap;
+}
+
+int smx_compute_guided_filter(const smx_params* p, const uint8_t* i, const float* cost,
+                              float* filter_cost, float* disp_map, uint8_t* mean, float* agg, int w,
+                              int h, int size_d, int dmin) {
+    SMX_ARG(p && i && cost && filter_cost && disp_map && size_d >= 1 && w >= 2 && h >= 1);
+    const size_t n = (size_t)w * h;
+    const size_t ws_bytes = pick_ws_bytes(w, h, size_d);
+    DevBuf dI, dC, dBest, dMap, dMean, dKeys, dAgg, ws;
+    SMX_HIP(dI.alloc(n));
+    SMX_HIP(dC.alloc(n * size_d * sizeof(float)));
+    SMX_HIP(dBest.alloc(n * sizeof(float)));
+    SMX_HIP(dMap.alloc(n * sizeof(float)));
+    SMX_HIP(dMean.alloc(n));
+    SMX_HIP(dKeys.alloc(n * sizeof(uint64_t)));
+    if (agg) SMX_HIP(dAgg.alloc(n * size_d * sizeof(float)));
+    SMX_HIP(ws.alloc(ws_bytes));
+    SMX_HIP(hipMemcpy(dI.p, i, n, hipMemcpyHostToDevice));
+    SMX_HIP(hipMemcpy(dC.p, cost, n * size_d * sizeof(float), hipMemcpyHostToDevice));
+    SMX_HIP(hipMemcpy(dBest.p, filter_cost, n * sizeof(float), hipMemcpyHostToDevice));
+    SMX_HIP(hipMemcpy(dMap.p, disp_map, n * sizeof(float), hipMemcpyHostToDevice));
+    int rc;
+    if ((rc = smx_dev_init_keys(dKeys.as<uint64_t>(), (int64_t)n, nullptr))) return rc;
+    if ((rc = smx_dev_aggregate_wta(p, dI.as<uint8_t>(), nullptr, dC.as<float>(), w, h, dmin, 0,
+                                    size_d, dKeys.as<uint64_t>(), dMean.as<uint8_t>(),
+                                    agg ? dAgg.as<float>() : nullptr, ws.p, ws_bytes, nullptr)))
+        return rc;
+    if ((rc = smx_dev_apply_keys(dKeys.as<uint64_t>(), (int64_t)n, dmin, dBest.as<float>(),
+                                 dMap.as<float>(), nullptr)))
+        return rc;
+    SMX_HIP(hipDeviceSynchronize());
+    SMX_HIP(hipMemcpy(filter_cost, dBest.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    SMX_HIP(hipMemcpy(disp_map, dMap.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    if (mean) SMX_HIP(hipMemcpy(mean, dMean.p, n, hipMemcpyDeviceToHost));
+    if (agg) SMX_HIP(hipMemcpy(agg, dAgg.p, n * size_d * sizeof(float), hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+int smx_detect_occlusion(const smx_params* p, float* disparityLeft, const float* disparityRight,
+                         int dOcclusion, int w, int h) {
+    SMX_ARG(p && disparityLeft && disparityRight && w >= 1 && h >= 1);
+    const size_t bytes = (size_t)w * h * sizeof(float);
+    DevBuf dL, dR;
+    SMX_HIP(dL.alloc(bytes));
+    SMX_HIP(dR.alloc(bytes));
+    SMX_HIP(hipMemcpy(dL.p, disparityLeft, bytes, hipMemcpyHostToDevice));
+    SMX_HIP(hipMemcpy(dR.p, disparityRight, bytes, hipMemcpyHostToDevice));
+    int rc = smx_dev_detect_occlusion(p, dL.as<float>(), dR.as<float>(), dOcclusion, w, h, nullptr);
+    if (rc) return rc;
+    SMX_HIP(hipDeviceSynchronize());
+    SMX_HIP(hipMemcpy(disparityLeft, dL.p, bytes, hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+int smx_fill_occlusion(float* disparity, int w, int h, float vMin) {
+    SMX_ARG(disparity && w >= 1 && h >= 1);
+    const size_t bytes = (size_t)w * h * sizeof(float);
+    DevBuf d;
+    SMX_HIP(d.alloc(bytes));
+    SMX_HIP(hipMemcpy(d.p, disparity, bytes, hipMemcpyHostToDevice));
+    int rc = smx_dev_fill_occlusion(d.as<float>(), w, h, vMin, nullptr);
+    if (rc) return rc;
+    SMX_HIP(hipDeviceSynchronize());
+    SMX_HIP(hipMemcpy(disparity, d.p, bytes, hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+int smx_stereo_pair(const smx_params* p, const uint8_t* gray_l, const uint8_t* gray_r, int w, int h,
+                    int size_d, int dminl, int dminr, const smx_pair_out* out) {
+    SMX_ARG(p && gray_l && gray_r && out && w >= 2 && h >= 1 && size_d >= 1);
+    const size_t n = (size_t)w * h;
+    const size_t fb = n * sizeof(float);
+    const size_t vb = fb * size_d;
+    const size_t ws_bytes = pick_ws_bytes(w, h, size_d);
+    DevBuf dL, dR, keysL, keysR, bestL, bestR, mapL, mapR, meanL, meanR, occ, fil, ws;
+    DevBuf costL, costR, aggL, aggR;
+    SMX_HIP(dL.alloc(n)); SMX_HIP(dR.alloc(n));
+    SMX_HIP(keysL.alloc(n * 8)); SMX_HIP(keysR.alloc(n * 8));
+    SMX_HIP(bestL.alloc(fb)); SMX_HIP(bestR.alloc(fb));
+    SMX_HIP(mapL.alloc(fb)); SMX_HIP(mapR.alloc(fb));
+    SMX_HIP(meanL.alloc(n)); SMX_HIP(meanR.alloc(n));
+    SMX_HIP(occ.alloc(fb)); SMX_HIP(fil.alloc(fb));
+    SMX_HIP(ws.alloc(ws_bytes));
+    if (out->cost_l) SMX_HIP(costL.alloc(vb));
+    if (out->cost_r) SMX_HIP(costR.alloc(vb));
+    if (out->agg_l) SMX_HIP(aggL.alloc(vb));
+    if (out->agg_r) SMX_HIP(aggR.alloc(vb));
+    SMX_HIP(hipMemcpy(dL.p, gray_l, n, hipMemcpyHostToDevice));
+    SMX_HIP(hipMemcpy(dR.p, gray_r, n, hipMemcpyHostToDevice));
+    int rc;
+    const int64_t nn = (int64_t)n;
+    // cost volumes are materialised only when the caller asks for them (main.cu:80-82);
+    // otherwise the slices are built on the fly inside the aggregation.
+    if (out->cost_l && (rc = smx_dev_cost_volume(p, dL.as<uint8_t>(), dR.as<uint8_t>(),
+                                                 costL.as<float>(), w, w, h, dminl, 0, size_d, nullptr)))
+        return rc;
+    if (out->cost_r && (rc = smx_dev_cost_volume(p, dR.as<uint8_t>(), dL.as<uint8_t>(),
+                                                 costR.as<float>(), w, w, h, dminr, 0, size_d, nullptr)))
+        return rc;
+    if ((rc = smx_dev_init_keys(keysL.as<uint64_t>(), nn, nullptr))) return rc;
+    if ((rc = smx_dev_init_keys(keysR.as<uint64_t>(), nn, nullptr))) return rc;
+    if ((rc = smx_dev_init_wta(bestL.as<float>(), mapL.as<float>(), nn, nullptr))) return rc;
+    if ((rc = smx_dev_init_wta(bestR.as<float>(), mapR.as<float>(), nn, nullptr))) return rc;
+    // main.cu:133-134
+    if ((rc = smx_dev_aggregate_wta(p, dL.as<uint8_t>(), dR.as<uint8_t>(),
+                                    out->cost_l ? costL.as<float>() : nullptr, w, h, dminl, 0, size_d,
+                                    keysL.as<uint64_t>(), meanL.as<uint8_t>(),
+                                    out->agg_l ? aggL.as<float>() : nullptr, ws.p, ws_bytes, nullptr)))
+        return rc;
+    if ((rc = smx_dev_aggregate_wta(p, dR.as<uint8_t>(), dL.as<uint8_t>(),
+                                    out->cost_r ? costR.as<float>() : nullptr, w, h, dminr, 0, size_d,
+                                    keysR.as<uint64_t>(), meanR.as<uint8_t>(),
+                                    out->agg_r ? aggR.as<float>() : nullptr, ws.p, ws_bytes, nullptr)))
+        return rc;
+    if ((rc = smx_dev_apply_keys(keysL.as<uint64_t>(), nn, dminl, bestL.as<float>(), mapL.as<float>(), nullptr))) return rc;
+    if ((rc = smx_dev_apply_keys(keysR.as<uint64_t>(), nn, dminr, bestR.as<float>(), mapR.as<float>(), nullptr))) return rc;
+    // main.cu:140-155
+    SMX_HIP(hipMemcpyAsync(occ.p, mapL.p, fb, hipMemcpyDeviceToDevice, nullptr));
+    if ((rc = smx_dev_detect_occlusion(p, occ.as<float>(), mapR.as<float>(), dminl - 100, w, h, nullptr))) return rc;
+    SMX_HIP(hipMemcpyAsync(fil.p, occ.p, fb, hipMemcpyDeviceToDevice, nullptr));
+    if ((rc = smx_dev_fill_occlusion(fil.as<float>(), w, h, (float)dminl, nullptr))) return rc;
+    SMX_HIP(hipDeviceSynchronize());
+    struct { void* dst; void* src; size_t b; } copies[] = {
+        {out->best_l, bestL.p, fb}, {out->best_r, bestR.p, fb}, {out->dmap_l, mapL.p, fb},
+        {out->dmap_r, mapR.p, fb},  {out->mean_l, meanL.p, n},  {out->mean_r, meanR.p, n},
+        {out->occlusion, occ.p, fb}, {out->filled, fil.p, fb},  {out->cost_l, costL.p, vb},
+        {out->cost_r, costR.p, vb}, {out->agg_l, aggL.p, vb},   {out->agg_r, aggR.p, vb},
+    };
+    for (auto& c : copies)
+        if (c.dst) SMX_HIP(hipMemcpy(c.dst, c.src, c.b, hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+}  // extern "C"

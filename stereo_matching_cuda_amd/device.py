@@ -1,0 +1,115 @@
+"""Device-resident pair pipeline: HBM buffers and streams come from PyTorch (plumbing only), all
+compute goes through the smx_dev_* C-ABI on torch's current HIP stream.
+
+One PairPipeline per (shape, slice range) per GPU; nothing is allocated after construction, so a
+step is a fixed sequence of kernel launches on one stream.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+_I64_MIN = -(1 << 63)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dp(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class PairPipeline:
+    """main.cu:65-155 for one stereo pair, optionally restricted to slices [s_begin, s_end) of
+    both volumes (the D-shard of this rank).  Layout in HBM: gray images u8 [h][w]; per view packed
+    WTA keys u64 [h][w]; best/dmap/occlusion/filled f32 [h][w]; workspace = 5 guidance planes +
+    5 volumes of `slices_in_flight` slices (see smx_agg_workspace_bytes)."""
+
+    def __init__(self, w, h, size_d, dminl=None, dminr=0, s_begin=0, s_end=None, device="cuda:0",
+                 slices_in_flight=None, want_agg=False, params=None, max_ws_bytes=64 << 30):
+        self.lib = _lib.lib()
+        self.w, self.h, self.size_d = int(w), int(h), int(size_d)
+        self.n = self.w * self.h
+        self.dminl = -(size_d - 1) if dminl is None else int(dminl)
+        self.dminr = int(dminr)
+        self.s_begin = int(s_begin)
+        self.s_end = self.size_d if s_end is None else int(s_end)
+        self.device = torch.device(device)
+        self.params = params if params is not None else _lib.default_params()
+        local = max(1, self.s_end - self.s_begin)
+        sif = local if slices_in_flight is None else max(1, min(local, int(slices_in_flight)))
+        while sif > 1 and self.lib.smx_agg_workspace_bytes(self.w, self.h, sif) > max_ws_bytes:
+            sif = (sif + 1) // 2
+        self.slices_in_flight = sif
+        self.ws_bytes = int(self.lib.smx_agg_workspace_bytes(self.w, self.h, sif))
+        dev = self.device
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        # keys[0] = left view, keys[1] = right view: one buffer so the shard merge is ONE all-reduce
+        self.keys = torch.empty((2, self.h, self.w), dtype=torch.int64, device=dev)
+        f = dict(dtype=torch.float32, device=dev)
+        self.best = torch.empty((2, self.h, self.w), **f)
+        self.dmap = torch.empty((2, self.h, self.w), **f)
+        self.mean = torch.empty((2, self.h, self.w), dtype=torch.uint8, device=dev)
+        self.occlusion = torch.empty((self.h, self.w), **f)
+        self.filled = torch.empty((self.h, self.w), **f)
+        self.agg = (torch.empty((2, local, self.h, self.w), **f) if want_agg else None)
+
+    # -- stages ------------------------------------------------------------------------------
+    def aggregate(self, gray_l, gray_r, cost_l=None, cost_r=None):
+        """Cost build (fused unless cost_* given) + guided-filter aggregation + running WTA of this
+        rank's slices, both views.  Leaves packed keys in self.keys."""
+        self.init_keys()
+        self.aggregate_view(0, gray_l, gray_r, cost_l)
+        self.aggregate_view(1, gray_r, gray_l, cost_r)
+
+    def init_keys(self):
+        _lib.check(self.lib.smx_dev_init_keys(_dp(self.keys), 2 * self.n, _stream()))
+
+    def aggregate_view(self, view, guide, other, cost=None):
+        L, P, st = self.lib, C.byref(self.params), _stream()
+        dmin = self.dminl if view == 0 else self.dminr
+        agg = self.agg[view] if self.agg is not None else None
+        _lib.check(L.smx_dev_aggregate_wta(
+            P, _dp(guide), _dp(other), _dp(cost), self.w, self.h, dmin, self.s_begin, self.s_end,
+            _dp(self.keys[view]), _dp(self.mean[view]), _dp(agg), _dp(self.ws), self.ws_bytes, st))
+
+    def finish(self):
+        """Keys -> best/dmap (reference presets, dispSelect rule), LR check, filling."""
+        L, P, st = self.lib, C.byref(self.params), _stream()
+        _lib.check(L.smx_dev_init_wta(_dp(self.best), _dp(self.dmap), 2 * self.n, st))
+        _lib.check(L.smx_dev_apply_keys(_dp(self.keys[0]), self.n, self.dminl, _dp(self.best[0]),
+                                        _dp(self.dmap[0]), st))
+        _lib.check(L.smx_dev_apply_keys(_dp(self.keys[1]), self.n, self.dminr, _dp(self.best[1]),
+                                        _dp(self.dmap[1]), st))
+        self.occlusion.copy_(self.dmap[0])                                   # main.cu:141
+        _lib.check(L.smx_dev_detect_occlusion(P, _dp(self.occlusion), _dp(self.dmap[1]),
+                                              self.dminl - 100, self.w, self.h, st))  # main.cu:149
+        self.filled.copy_(self.occlusion)                                    # main.cu:153
+        _lib.check(L.smx_dev_fill_occlusion(_dp(self.filled), self.w, self.h, float(self.dminl), st))
+
+    def run(self, gray_l, gray_r):
+        self.aggregate(gray_l, gray_r)
+        self.finish()
+
+    # -- key helpers for the shard merge -------------------------------------------------------
+    def keys_signed(self):
+        """In place: u64 keys -> order-preserving i64 (flip the top bit) for a signed MIN reduce."""
+        self.keys.bitwise_xor_(_I64_MIN)
+        return self.keys
+
+    def keys_unsigned(self):
+        self.keys.bitwise_xor_(_I64_MIN)
+        return self.keys
+
+    def results(self):
+        """Host copies (numpy) named like the oracle's dict."""
+        torch.cuda.synchronize(self.device)
+        c = lambda t: t.detach().cpu().numpy()
+        r = {"bestl": c(self.best[0]), "bestr": c(self.best[1]), "dmapl": c(self.dmap[0]),
+             "dmapr": c(self.dmap[1]), "meanl": c(self.mean[0]), "meanr": c(self.mean[1]),
+             "occlusion": c(self.occlusion), "filled": c(self.filled)}
+        if self.agg is not None:
+            r["aggl"], r["aggr"] = c(self.agg[0]), c(self.agg[1])
+        return r

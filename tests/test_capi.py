@@ -1,0 +1,94 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports
+every symbol include/smx.h declares with the signatures the ctypes binding assumes.  No compute
+call is made here (no GPU in the authoring container)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import stereo_matching_cuda_amd as smx
+from stereo_matching_cuda_amd import _lib
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.SO_PATH):
+        smx.build()
+    return _lib.lib()
+
+
+def _declared_functions():
+    src = open(_lib.HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(smx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree(lib):
+    declared = _declared_functions()
+    assert declared, "no functions parsed from include/smx.h"
+    assert sorted(_lib.SIGNATURES) == declared
+    for name in declared:
+        assert hasattr(lib, name), f"libsmx_hip.so lacks {name}"
+
+
+def test_default_params_match_reference_macros(lib):
+    p = smx.default_params()  # SystemIncludes.h:7-24
+    assert (p.r_w, p.g_w, p.b_w) == (0.299, 0.587, 0.0721)
+    assert (p.alpha, p.th_color, p.th_grad, p.radius, p.eps, p.d_lr) == (0.9, 7, 2, 9, 6.5025, 0)
+
+
+def test_struct_layout_matches_oracle_params(orc):
+    assert C.sizeof(_lib.Params) == C.sizeof(orc.Params)
+    assert [f[0] for f in _lib.Params._fields_] == [f[0] for f in orc.Params._fields_]
+
+
+def test_pack_key_host_matches_oracle(lib, orc):
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([rng.normal(size=100).astype(np.float32),
+                           np.array([0.0, -0.0, 2.5, 3.3961514e38], np.float32)])
+    for v in vals:
+        for s in (0, 1, 191, 511):
+            k = lib.smx_pack_key(float(v), s)
+            assert k == int(orc.lib().orc_pack_key(float(v), s))
+            c, sl = C.c_float(), C.c_uint32()
+            lib.smx_unpack_key(k, C.byref(c), C.byref(sl))
+            assert sl.value == s and np.float32(c.value) == (np.float32(0) if v == 0 else v)
+
+
+def test_argument_errors_do_not_need_a_gpu(lib):
+    p = smx.default_params()
+    rc = lib.smx_compute_cost(C.byref(p), None, None, None, 4, 4, 4, 4, 1, 0)
+    assert rc == -1 and b"bad argument" in lib.smx_last_error()
+    buf = np.zeros(16, np.uint8)
+    ptr = buf.ctypes.data_as(C.c_void_p)
+    rc = lib.smx_compute_cost(C.byref(p), ptr, ptr, ptr, 4, 5, 4, 4, 1, 0)  # w1 != w2
+    assert rc == -1
+    assert lib.smx_agg_workspace_bytes(0, 4, 1) == 0
+    assert lib.smx_agg_workspace_bytes(1242, 375, 192) > 5 * 192 * 1242 * 375 * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "SO_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.lib()
+
+
+@pytest.mark.skipif(smx._lib.lib().smx_device_count() > 0, reason="a GPU is present")
+def test_compute_without_gpu_raises_not_falls_back():
+    img = np.zeros((8, 8), np.uint8)
+    with pytest.raises(smx.SmxError):
+        smx.compute_cost(img, img, 2, 0)
+
+
+def test_write_mat_matches_reference_normaliser(orc):
+    rng = np.random.default_rng(3)
+    for _ in range(5):
+        m = rng.normal(size=(17, 23)).astype(np.float32) * 10
+        assert np.array_equal(smx.write_mat(m), orc.write_mat_u8(m))
+    m = np.array([[3, 1, 2], [0, 5, -1]], np.float32)  # min seen only via the else-branch
+    assert np.array_equal(smx.write_mat(m), orc.write_mat_u8(m))
+    m = np.arange(12, dtype=np.float32).reshape(3, 4)   # strictly increasing: min never updated
+    assert np.array_equal(smx.write_mat(m), orc.write_mat_u8(m))
