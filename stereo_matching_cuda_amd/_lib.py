@@ -75,6 +75,27 @@ SIGNATURES = {
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, SONAME
+    libamdhip64.so.7).  Two HIP runtimes in one process cannot both own the GPU, and device buffers,
+    streams and RCCL come from torch, so when torch is installed its runtime is mapped first and
+    libsmx_hip.so (NEEDED libamdhip64.so.7) binds to that same copy.  Without torch (e.g. the C++
+    host build) the system runtime under /opt/rocm is used.  SMX_HIP_RUNTIME=system skips this."""
+    if os.environ.get("SMX_HIP_RUNTIME", "") == "system":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return None
+        path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            return C.CDLL(path, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+    return None
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -84,6 +105,7 @@ def lib():
                 "`python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C stereo_matching_cuda_amd/csrc` (needs /opt/rocm/bin/hipcc). "
                 "There is no CPU fallback.")
+        _preload_torch_hip_runtime()
         L = C.CDLL(SO_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError if the library lacks a declared symbol
