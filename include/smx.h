@@ -146,6 +146,13 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
                           uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Aggregation implementation: 0 = auto (fused strip-walker kernels when the cost is built on the
+ * fly and radius <= 9, else the multi-kernel path), 1 = force multi-kernel, 2 = force fused (error
+ * if not applicable).  Process-wide; for tests and A/B timing.  smx_last_agg_path() reports which
+ * one the last smx_dev_aggregate_wta call on this thread used (1 or 2). */
+int smx_set_agg_path(int path);
+int smx_last_agg_path(void);
+
 /* winner_take_all.cuh (live WTA = dispSelectOnGPU, guidedFilter.cu:403-411), packed form. */
 int smx_dev_init_keys(uint64_t* d_keys, int64_t n, void* stream);
 /* Fold keys into best/dmap with the reference's rule: if (best >= q) { dmap = dmin + slice;

@@ -68,6 +68,8 @@ SIGNATURES = {
     "smx_dev_fill_occlusion": (_i, [_vp, _i, _i, _f, _vp]),
     "smx_pack_key": (_u64, [_f, _u32]),
     "smx_unpack_key": (None, [_u64, C.POINTER(_f), C.POINTER(_u32)]),
+    "smx_set_agg_path": (_i, [_i]),
+    "smx_last_agg_path": (_i, []),
     "smx_set_timing": (_i, [_i]),
     "smx_last_agg_ms": (_i, [C.POINTER(_f), C.POINTER(_i)]),
 }

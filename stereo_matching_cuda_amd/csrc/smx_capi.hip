@@ -14,6 +14,15 @@ static thread_local bool g_timing = false;
 static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static thread_local bool g_ev_valid = false;
 static thread_local int g_launches = 0;
+static int g_agg_path = 0;                 // 0 auto, 1 force v1 (multi-kernel), 2 force v2 (fused)
+static thread_local int g_last_path = 0;
+
+// smx_agg_v2.hip
+bool v2_supported(const smx_params* p);
+size_t v2_workspace_bytes(int w, int h, int R, int nslices);
+int aggregate_v2(const smx_params* p, const uint8_t* d_guide, const uint8_t* d_other, int w, int h,
+                 int dmin, int s_begin, int s_end, uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg,
+                 void* d_ws, size_t ws_bytes, hipStream_t st, int* launches);
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -52,7 +61,7 @@ void smx_default_params(smx_params* p) {
 
 const char* smx_last_error(void) { return g_err.c_str(); }
 
-const char* smx_version(void) { return "smx-hip gfx950 0.1 (v1 dataflow)"; }
+const char* smx_version(void) { return "smx-hip gfx950 0.2 (fused strip-walker aggregation)"; }
 
 int smx_device_count(void) {
     int n = 0;
@@ -113,9 +122,19 @@ int smx_dev_integral(const float* d_in, float* d_out, int w, int h, int nplanes,
 
 size_t smx_agg_workspace_bytes(int w, int h, int nslices) {
     if (w < 1 || h < 1 || nslices < 1) return 0;
-    // guidance: im, mean_im, cinv, S_im, S_sq ; per slice in flight: cost, T0, T1, A, B
-    return plane_bytes(w, h) * (5 + 5 * (size_t)nslices) + WS_ALIGN;
+    // v1 path: guidance im, mean_im, cinv, S_im, S_sq ; per slice in flight: cost, T0, T1, A, B
+    const size_t v1 = plane_bytes(w, h) * (5 + 5 * (size_t)nslices) + WS_ALIGN;
+    const size_t v2b = v2_workspace_bytes(w, h, -1, nslices);
+    return v1 > v2b ? v1 : v2b;
 }
+
+int smx_set_agg_path(int path) {
+    if (path < 0 || path > 2) return fail(SMX_E_ARG, "smx_set_agg_path: path must be 0, 1 or 2");
+    g_agg_path = path;
+    return SMX_OK;
+}
+
+int smx_last_agg_path(void) { return g_last_path; }
 
 int smx_dev_init_keys(uint64_t* d_keys, int64_t n, void* stream) {
     SMX_ARG(d_keys && n > 0);
@@ -152,6 +171,25 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
     SMX_ARG(d_cost || d_other);
     SMX_ARG(w >= 2 && h >= 1 && s_begin >= 0 && s_end >= s_begin && p->radius >= 0);
     hipStream_t st = (hipStream_t)stream;
+    // fused path: cost built on the fly, radius <= 9 (smx_agg_v2.hip)
+    const bool can_v2 = !d_cost && d_other && v2_supported(p);
+    if (g_agg_path == 2 && !can_v2)
+        return fail(SMX_E_ARG, "smx_dev_aggregate_wta: fused path forced but not applicable "
+                               "(needs d_cost == NULL, d_other != NULL, radius <= 9)");
+    if (can_v2 && g_agg_path != 1) {
+        g_launches = 0;
+        if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
+        int rc2 = aggregate_v2(p, d_guide, d_other, w, h, dmin, s_begin, s_end, d_keys, d_mean_u8,
+                               d_agg, d_workspace, workspace_bytes, st, &g_launches);
+        if (rc2) return rc2;
+        if (g_timing) {
+            SMX_HIP(hipEventRecord(g_ev1, st));
+            g_ev_valid = true;
+        }
+        g_last_path = 2;
+        return SMX_OK;
+    }
+    g_last_path = 1;
     const size_t pb = plane_bytes(w, h);
     const int64_t n = (int64_t)w * h;
     char* base = (char*)align_up((size_t)d_workspace, WS_ALIGN);

@@ -198,27 +198,60 @@ def test_pair_tsukuba_against_committed_outputs(tsukuba_gray, tsukuba_oracle, go
     _eq(r["meanl"], golden["image_mean_left"], "mean png")
 
 
-def _device_pair(Il, Ir, D, **kw):
+def _device_pair(Il, Ir, D, path=2, **kw):
+    """path: 2 = fused strip-walker aggregation (the default product path), 1 = multi-kernel path."""
     import torch
     from stereo_matching_cuda_amd.device import PairPipeline
     h, w = Il.shape
     dl = torch.from_numpy(Il).cuda()
     dr = torch.from_numpy(Ir).cuda()
     pipe = PairPipeline(w, h, D, **kw)
-    pipe.run(dl, dr)
+    smx.lib().smx_set_agg_path(path)
+    try:
+        pipe.run(dl, dr)
+        assert smx.lib().smx_last_agg_path() == path
+    finally:
+        smx.lib().smx_set_agg_path(0)
     return pipe.results()
 
 
-def test_device_pipeline_tsukuba_fused_cost(tsukuba_gray, tsukuba_oracle):
+@pytest.mark.parametrize("path", [2, 1])
+def test_device_pipeline_tsukuba_fused_cost(tsukuba_gray, tsukuba_oracle, path):
     Il, Ir = tsukuba_gray
-    r = _device_pair(Il, Ir, 16, dminl=-15, dminr=0, want_agg=True)
+    r = _device_pair(Il, Ir, 16, path=path, dminl=-15, dminr=0, want_agg=True)
     for k in KEYS + ("aggl", "aggr"):
         _eq(r[k], tsukuba_oracle[k], k)
 
 
-def test_device_pipeline_chunked_equals_unchunked(tsukuba_gray, tsukuba_oracle):
+def test_default_path_is_the_fused_one(tsukuba_gray):
+    import torch
+    from stereo_matching_cuda_amd.device import PairPipeline
     Il, Ir = tsukuba_gray
-    r = _device_pair(Il, Ir, 16, dminl=-15, dminr=0, slices_in_flight=3)
+    pipe = PairPipeline(384, 288, 16)
+    pipe.run(torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda())
+    assert smx.lib().smx_last_agg_path() == 2
+
+
+@pytest.mark.parametrize("w,h,D", [(2, 1, 2), (20, 20, 3), (19, 40, 4), (64, 9, 2), (129, 70, 5),
+                                   (94, 65, 6), (113, 130, 7), (93, 64, 3), (187, 129, 20),
+                                   (300, 200, 70)])
+def test_fused_path_small_and_ragged(orc, w, h, D):
+    """Strip / sub-strip / band / ring boundaries of the fused kernels (TW=112, OW=93, SUBW=28,
+    BH=64, ring 84 rows), images smaller than one tile, disparity ranges wider than the image."""
+    rng = np.random.default_rng(w * 7 + h * 3 + D)
+    base = rng.integers(0, 256, size=(h, w + D), dtype=np.uint8)
+    Il = np.ascontiguousarray(base[:, :w])
+    Ir = np.ascontiguousarray(base[:, D // 2: D // 2 + w])
+    want = orc.stereo_pair(Il, Ir, D, want_agg=True)
+    r = _device_pair(Il, Ir, D, want_agg=True)
+    for k in KEYS + ("aggl", "aggr"):
+        _eq(r[k], want[k], k)
+
+
+@pytest.mark.parametrize("path", [2, 1])
+def test_device_pipeline_chunked_equals_unchunked(tsukuba_gray, tsukuba_oracle, path):
+    Il, Ir = tsukuba_gray
+    r = _device_pair(Il, Ir, 16, path=path, dminl=-15, dminr=0, slices_in_flight=3)
     for k in KEYS:
         _eq(r[k], tsukuba_oracle[k], k)
 
