@@ -44,6 +44,8 @@ constexpr int BH = 64;             // band height = wave width
 constexpr int RMAX = 9;            // largest supported box radius
 constexpr int RR = BH + 2 * RMAX + 2;  // ring rows (84)
 constexpr int PITCH = TW + 1;      // odd pitch: LANE=ROW accesses hit distinct banks
+constexpr int RBATCH = 14;         // columns per load batch in phase R (SUBW = 2 batches)
+constexpr int PB = 4;              // output columns per load batch in phase B
 
 enum Mode { GUID = 0, S1 = 1, S2 = 2 };
 
@@ -65,7 +67,10 @@ __device__ __forceinline__ int seg_c0(const Args& a, int g) {
     return (g >> 2) * a.ow - (a.R + 1) + (g & 3) * SUBW;
 }
 
-// One column of the two scanned quantities for row y (LANE = ROW; all loads are 256-B coalesced).
+// The two scanned quantities of NB consecutive columns of row y (LANE = ROW; every load is a 256-B
+// coalesced row of a transposed plane).  All global loads of a batch are issued before the first
+// use, so one batch exposes one memory latency instead of NB.  Columns outside [0, w) are clamped
+// (their values are never accumulated).
 template <int MODE>
 struct Source {
     const float *f1, *g1, *f2, *g2, *sa, *sb;
@@ -78,29 +83,49 @@ struct Source {
         sa = MODE == S2 ? a.srcA + (size_t)slice * plane + y : nullptr;
         sb = MODE == S2 ? a.srcB + (size_t)slice * plane + y : nullptr;
     }
-    __device__ __forceinline__ void load(int c, float& v0, float& v1) const {
+    template <int NB>
+    __device__ __forceinline__ void load(int c0, float (&v0)[NB], float (&v1)[NB]) const {
         if (MODE == GUID) {
-            float v = f1[(size_t)(c + 1) * hp];
-            v0 = v;            // chToFlOnGPU
-            v1 = v * v;        // pixelMultOnGPU(d_im, d_im)
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                int c = c0 + t;
+                c = c < 0 ? 0 : (c >= w ? w - 1 : c);
+                v0[t] = f1[(size_t)(c + 1) * hp];      // chToFlOnGPU
+            }
+#pragma unroll
+            for (int t = 0; t < NB; ++t) v1[t] = v0[t] * v0[t];   // pixelMultOnGPU(d_im, d_im)
         } else if (MODE == S1) {
-            int xx = c + d;
-            xx = xx < -1 ? -1 : (xx > w ? w : xx);      // sentinel columns at -1 and w
-            const size_t o1 = (size_t)(c + 1) * hp, o2 = (size_t)(xx + 1) * hp;
-            float a1 = f1[o1], b1 = g1[o1], a2 = f2[o2], b2 = g2[o2];
-            float t1 = fabsf(a1 - a2);
-            float t2 = fabsf(b1 - b2);
-            float m1 = t1 < cc.th_color ? t1 : cc.th_color;
-            float m2 = t2 < cc.th_grad ? t2 : cc.th_grad;
-            float x = cc.oma * m1;
-            float z = cc.alpha * m2;
-            float p = x + z;   // costVolume.cu:187
-            v0 = p;
-            v1 = a1 * p;       // pixelMultOnGPU(d_im, d_pki) guidedFilter.cu:209
+            float a2[NB], b1[NB], b2[NB];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                int c = c0 + t;
+                c = c < 0 ? 0 : (c >= w ? w - 1 : c);
+                int xx = c + d;
+                xx = xx < -1 ? -1 : (xx > w ? w : xx);  // sentinel columns at -1 and w
+                const size_t o1 = (size_t)(c + 1) * hp, o2 = (size_t)(xx + 1) * hp;
+                v1[t] = f1[o1]; b1[t] = g1[o1]; a2[t] = f2[o2]; b2[t] = g2[o2];
+            }
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                float t1 = fabsf(v1[t] - a2[t]);
+                float t2 = fabsf(b1[t] - b2[t]);
+                float m1 = t1 < cc.th_color ? t1 : cc.th_color;
+                float m2 = t2 < cc.th_grad ? t2 : cc.th_grad;
+                float x = cc.oma * m1;
+                float z = cc.alpha * m2;
+                float p = x + z;        // costVolume.cu:187
+                v0[t] = p;
+                v1[t] = v1[t] * p;      // pixelMultOnGPU(d_im, d_pki) guidedFilter.cu:209
+            }
         } else {
-            const size_t o = (size_t)c * hp;
-            v0 = sa[o];
-            v1 = sb[o];
+#pragma unroll
+            for (int t = 0; t < NB; ++t) {
+                int c = c0 + t;
+                c = c < 0 ? 0 : (c >= w ? w - 1 : c);
+                const size_t o = (size_t)c * hp;
+                v0[t] = sa[o];
+                v1[t] = sb[o];
+            }
         }
     }
 };
@@ -134,6 +159,8 @@ __global__ __launch_bounds__(64) void k_v2_prep(const uint8_t* __restrict__ I, f
 // ---------------------------------------------------------------------------------------------
 // carry prepass.  grid (nbands, nslices), block 64 (LANE = ROW).
 // ---------------------------------------------------------------------------------------------
+constexpr int CB = 16;  // columns per load batch of the carry prepass
+
 template <int MODE>
 __global__ __launch_bounds__(64) void k_v2_carry(Args a) {
     const int slice = blockIdx.y;
@@ -143,20 +170,35 @@ __global__ __launch_bounds__(64) void k_v2_carry(Args a) {
     float* c0p = a.carry + ((size_t)(slice * 2 + 0) * a.nsegs) * a.hp + y;
     float* c1p = a.carry + ((size_t)(slice * 2 + 1) * a.nsegs) * a.hp + y;
     float acc0 = -0.0f, acc1 = -0.0f;
-    for (int g = 0; g < a.nsegs; ++g) {
+    int g = 0;
+    // segments that start at or left of column 0 begin with the additive identity
+    while (g < a.nsegs && seg_c0(a, g) <= 0) {
         c0p[(size_t)g * a.hp] = acc0;
         c1p[(size_t)g * a.hp] = acc1;
-        int cb = seg_c0(a, g);
-        int ce = (g + 1 < a.nsegs) ? seg_c0(a, g + 1) : a.w;
-        cb = cb < 0 ? 0 : cb;
-        ce = ce > a.w ? a.w : ce;
-#pragma unroll 4
-        for (int c = cb; c < ce; ++c) {
-            float v0, v1;
-            src.load(c, v0, v1);
-            acc0 = v0 + acc0;
-            acc1 = v1 + acc1;
+        ++g;
+    }
+    int next = g < a.nsegs ? seg_c0(a, g) : 0x7fffffff;
+    for (int cb = 0; cb < a.w; cb += CB) {
+        float v0[CB], v1[CB];
+        src.template load<CB>(cb, v0, v1);
+#pragma unroll
+        for (int t = 0; t < CB; ++t) {
+            const int c = cb + t;
+            if (c < a.w) {
+                if (c == next) {   // wave-uniform: carry of segment g = row sum left of column c
+                    c0p[(size_t)g * a.hp] = acc0;
+                    c1p[(size_t)g * a.hp] = acc1;
+                    ++g;
+                    next = g < a.nsegs ? seg_c0(a, g) : 0x7fffffff;
+                }
+                acc0 = v0[t] + acc0;
+                acc1 = v1[t] + acc1;
+            }
         }
+    }
+    for (; g < a.nsegs; ++g) {     // segments starting at or beyond column w are never read
+        c0p[(size_t)g * a.hp] = acc0;
+        c1p[(size_t)g * a.hp] = acc1;
     }
 }
 
@@ -177,6 +219,11 @@ __global__ __launch_bounds__(256) void k_v2_walk(Args a) {
     // phase C ownership: thread -> (integral, column of the tile)
     const int ci = tid / TW, cj = tid - ci * TW;
     float S = -0.0f;
+    const float* __restrict__ meanT = a.meanT;
+    const float* __restrict__ cinvT = a.cinvT;
+    const float* __restrict__ srcF1 = a.F1;
+    float* __restrict__ dstA = a.dstA;
+    float* __restrict__ dstB = a.dstB;
 
     for (int b = 0; b < nbands; ++b) {
         const int y0 = b * BH;
@@ -193,16 +240,19 @@ __global__ __launch_bounds__(256) void k_v2_walk(Args a) {
             float* r0 = &ring[0][rr][j0];
             float* r1 = &ring[1][rr][j0];
             const int cbeg = cs + j0;
-#pragma unroll 4
-            for (int j = 0; j < SUBW; ++j) {
-                const int c = cbeg + j;
-                if (c >= 0 && c < w) {
-                    float v0, v1;
-                    src.load(c, v0, v1);
-                    acc0 = v0 + acc0;
-                    acc1 = v1 + acc1;
-                    r0[j] = acc0;
-                    r1[j] = acc1;
+#pragma unroll
+            for (int jb = 0; jb < SUBW; jb += RBATCH) {
+                float v0[RBATCH], v1[RBATCH];
+                src.template load<RBATCH>(cbeg + jb, v0, v1);
+#pragma unroll
+                for (int t = 0; t < RBATCH; ++t) {
+                    const int c = cbeg + jb + t;
+                    if (c >= 0 && c < w) {
+                        acc0 = v0[t] + acc0;
+                        acc1 = v1[t] + acc1;
+                        r0[jb + t] = acc0;
+                        r1[jb + t] = acc1;
+                    }
                 }
             }
         }
@@ -210,7 +260,23 @@ __global__ __launch_bounds__(256) void k_v2_walk(Args a) {
         // ---------------- phase C: LANE = COLUMN, R -> S in place ------------------------------
         if (ci < 2) {
             int rr = ring_row(y0);
-            for (int r = 0; r < rows; ++r) {
+            int r = 0;
+            for (; r + 8 <= rows; r += 8) {
+                float v[8];
+                int ro[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    ro[t] = rr;
+                    v[t] = ring[ci][rr][cj];
+                    rr = (rr + 1 == RR) ? 0 : rr + 1;
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    S = v[t] + S;
+                    ring[ci][ro[t]][cj] = S;
+                }
+            }
+            for (; r < rows; ++r) {
                 float v = ring[ci][rr][cj];
                 S = v + S;
                 ring[ci][rr][cj] = S;
@@ -228,46 +294,62 @@ __global__ __launch_bounds__(256) void k_v2_walk(Args a) {
             const int ych = ymax - (hy ? ymin : -1);
             const int rr1 = ring_row(ymax);
             const int rr0 = ring_row(hy ? ymin : 0);
-            for (int m = wave; m < a.ow; m += NSUB) {
-                const int xo = xs + m;
-                if (xo >= w) break;
-                const int xmax = min(w - 1, xo + R);
-                const int jmax = xmax - cs;
-                const bool hx = (xo - R - 1) >= 0;
-                const int jmin = m;  // (xo - R - 1) - cs
-                const int xcw = xmax - (hx ? xo - R - 1 : -1);
-                const float area = (float)(xcw * ych);
-                float val0 = ring[0][rr1][jmax];
-                float val1 = ring[1][rr1][jmax];
-                if (hx) { val0 -= ring[0][rr1][jmin]; val1 -= ring[1][rr1][jmin]; }
-                if (hy) { val0 -= ring[0][rr0][jmax]; val1 -= ring[1][rr0][jmax]; }
-                if (hx && hy) { val0 += ring[0][rr0][jmin]; val1 += ring[1][rr0][jmin]; }
-                const float m0 = 1.0f * val0 / area;
-                const float m1 = 1.0f * val1 / area;
-                const size_t T = (size_t)xo * hp + yo;
-                if (MODE == GUID) {
-                    float mm = m0 * m0;          // pixelMultOnGPU(mean, mean) guidedFilter.cu:112
-                    float var = m1 - mm;         // pixelSousOnGPU :121
-                    float c = (float)(1.0f / ((double)var + a.eps));   // :350
-                    a.dstA[T] = m0;
-                    a.dstB[T] = c;
-                    if (a.mean_u8) {             // flToChOnGPU :451-458
-                        int ci8 = (int)m0;
-                        a.mean_u8[(size_t)yo * w + xo] = (ci8 > 255) ? 255 : (uint8_t)ci8;
+            for (int mb = wave; mb < a.ow; mb += NSUB * PB) {
+                // global operands of PB output columns first (one exposed latency per batch)
+                float ga[PB], gb[PB];
+#pragma unroll
+                for (int t = 0; t < PB; ++t) {
+                    const int m = mb + t * NSUB;
+                    int xo = xs + m;
+                    xo = (m < a.ow && xo < w) ? xo : (w - 1);
+                    const size_t T = (size_t)xo * hp + yo;
+                    if (MODE == S1) { ga[t] = meanT[T]; gb[t] = cinvT[T]; }
+                    if (MODE == S2) { ga[t] = srcF1[(size_t)(xo + 1) * hp + yo]; gb[t] = 0.0f; }
+                    if (MODE == GUID) { ga[t] = 0.0f; gb[t] = 0.0f; }
+                }
+#pragma unroll
+                for (int t = 0; t < PB; ++t) {
+                    const int m = mb + t * NSUB;
+                    const int xo = xs + m;
+                    if (m < a.ow && xo < w) {
+                        const int xmax = min(w - 1, xo + R);
+                        const int jmax = xmax - cs;
+                        const bool hx = (xo - R - 1) >= 0;
+                        const int jmin = m;  // (xo - R - 1) - cs
+                        const int xcw = xmax - (hx ? xo - R - 1 : -1);
+                        const float area = (float)(xcw * ych);
+                        float val0 = ring[0][rr1][jmax];
+                        float val1 = ring[1][rr1][jmax];
+                        if (hx) { val0 -= ring[0][rr1][jmin]; val1 -= ring[1][rr1][jmin]; }
+                        if (hy) { val0 -= ring[0][rr0][jmax]; val1 -= ring[1][rr0][jmax]; }
+                        if (hx && hy) { val0 += ring[0][rr0][jmin]; val1 += ring[1][rr0][jmin]; }
+                        const float m0 = 1.0f * val0 / area;
+                        const float m1 = 1.0f * val1 / area;
+                        const size_t T = (size_t)xo * hp + yo;
+                        if (MODE == GUID) {
+                            float mm = m0 * m0;          // pixelMultOnGPU(mean, mean) guidedFilter.cu:112
+                            float var = m1 - mm;         // pixelSousOnGPU :121
+                            float c = (float)(1.0f / ((double)var + a.eps));   // :350
+                            dstA[T] = m0;
+                            dstB[T] = c;
+                            if (a.mean_u8) {             // flToChOnGPU :451-458
+                                int ci8 = (int)m0;
+                                a.mean_u8[(size_t)yo * w + xo] = (ci8 > 255) ? 255 : (uint8_t)ci8;
+                            }
+                        } else if (MODE == S1) {
+                            float mI = ga[t];
+                            float c = gb[t];
+                            float mm = mI * m0;          // compute_ak_and_bk guidedFilter.cu:345-354
+                            float ak = 1.0f * (m1 - mm) * c;
+                            float mb2 = 1.0f * mI * ak;
+                            float bk = 1.0f * m0 - mb2;
+                            dstA[(size_t)slice * plane + T] = ak;
+                            dstB[(size_t)slice * plane + T] = bk;
+                        } else {
+                            float tq = m0 * ga[t];       // compute_q guidedFilter.cu:363-369
+                            dstA[(size_t)slice * plane + T] = tq + m1;
+                        }
                     }
-                } else if (MODE == S1) {
-                    float mI = a.meanT[T];
-                    float c = a.cinvT[T];
-                    float mm = mI * m0;          // compute_ak_and_bk guidedFilter.cu:345-354
-                    float ak = 1.0f * (m1 - mm) * c;
-                    float mb = 1.0f * mI * ak;
-                    float bk = 1.0f * m0 - mb;
-                    a.dstA[(size_t)slice * plane + T] = ak;
-                    a.dstB[(size_t)slice * plane + T] = bk;
-                } else {
-                    float I = a.F1[(size_t)(xo + 1) * hp + yo];
-                    float t = m0 * I;            // compute_q guidedFilter.cu:363-369
-                    a.dstA[(size_t)slice * plane + T] = t + m1;
                 }
             }
         }
