@@ -146,6 +146,16 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
                           uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
                           size_t workspace_bytes, void* stream);
 
+/* Both views of a stereo pair in one call (main.cu:133-134 back to back): every kernel launch
+ * covers the left and the right volume, which halves the launch count and hides the latency-bound
+ * prepasses.  View 0 = left (guide d_left, labels dminl + s), view 1 = right (guide d_right, labels
+ * dminr + s).  d_keys: 2*n keys (left then right); d_mean_u8: NULL or 2*n bytes; d_agg: NULL or two
+ * volumes of (s_end - s_begin)*n floats.  Workspace: >= 2 * smx_agg_workspace_bytes(w, h, nslices). */
+int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const uint8_t* d_right,
+                               int w, int h, int dminl, int dminr, int s_begin, int s_end,
+                               uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* Aggregation implementation: 0 = auto (fused strip-walker kernels when the cost is built on the
  * fly and radius <= 9, else the multi-kernel path), 1 = force multi-kernel, 2 = force fused (error
  * if not applicable).  Process-wide; for tests and A/B timing.  smx_last_agg_path() reports which

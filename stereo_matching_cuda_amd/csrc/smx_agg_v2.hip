@@ -37,15 +37,19 @@
 namespace smx {
 namespace v2 {
 
-constexpr int TW = 112;            // columns of S computed per strip
+constexpr int TW = 104;            // columns of S computed per strip
 constexpr int NSUB = 4;            // sub-strips per strip = waves per workgroup
-constexpr int SUBW = TW / NSUB;    // 28
+constexpr int SUBW = TW / NSUB;    // 26
 constexpr int BH = 64;             // band height = wave width
 constexpr int RMAX = 9;            // largest supported box radius
-constexpr int RR = BH + 2 * RMAX + 2;  // ring rows (84)
+constexpr int RR = 96;             // ring rows >= BH + 2*RMAX + 2; multiple of 32 so that the wrap
+                                   // of a band inside the ring does not shift LDS banks
 constexpr int PITCH = TW + 1;      // odd pitch: LANE=ROW accesses hit distinct banks
-constexpr int RBATCH = 14;         // columns per load batch in phase R (SUBW = 2 batches)
+constexpr int RBATCH = 13;         // columns per load batch in phase R (SUBW = 2 batches)
 constexpr int PB = 4;              // output columns per load batch in phase B
+constexpr int CB = 16;             // columns per load batch of the carry prepass
+static_assert(RR >= BH + 2 * RMAX + 2 && RR % 32 == 0, "ring too small");
+static_assert(SUBW % RBATCH == 0 && 2 * TW <= 256, "tile geometry");
 
 enum Mode { GUID = 0, S1 = 1, S2 = 2 };
 
@@ -63,8 +67,23 @@ struct Args {
     double eps;
 };
 
+// Both views of a pair travel in one launch: blockIdx.z selects the view.
+struct Launch {
+    Args v[2];
+};
+
 __device__ __forceinline__ int seg_c0(const Args& a, int g) {
     return (g >> 2) * a.ow - (a.R + 1) + (g & 3) * SUBW;
+}
+
+// x / d, correctly rounded, for an integer-valued d in [1, 361] with r = RN(1/d): one residual
+// correction step (Markstein).  Bit-identical to IEEE division for |x| >= 2^-100 (checked on 5.7e9
+// samples over all window areas, tools/check_fastdiv.c); callers route smaller |x| (incl. +-0, whose
+// sign the correction would lose) to the true division.
+__device__ __forceinline__ float div_small_int(float x, float d, float r) {
+    float q = x * r;
+    float e = __builtin_fmaf(-q, d, x);
+    return __builtin_fmaf(e, r, q);
 }
 
 // The two scanned quantities of NB consecutive columns of row y (LANE = ROW; every load is a 256-B
@@ -132,10 +151,18 @@ struct Source {
 
 // ---------------------------------------------------------------------------------------------
 // prep: u8 image [h][w] -> F_T, G_T [(x+1)*hp + y], sentinel columns x = -1 and x = w.
-// grid (ceil(hp/64), w + 2), block 64.
+// grid (ceil(hp/64), w + 2, nimages), block 64.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_v2_prep(const uint8_t* __restrict__ I, float* __restrict__ F,
-                                                float* __restrict__ G, int w, int h, int hp) {
+struct PrepArgs {
+    const uint8_t* I[2];
+    float* F[2];
+    float* G[2];
+};
+
+__global__ __launch_bounds__(64) void k_v2_prep(PrepArgs pa, int w, int h, int hp) {
+    const uint8_t* __restrict__ I = pa.I[blockIdx.z];
+    float* __restrict__ F = pa.F[blockIdx.z];
+    float* __restrict__ G = pa.G[blockIdx.z];
     const int y = blockIdx.x * 64 + threadIdx.x;
     const int x = (int)blockIdx.y - 1;
     if (y >= hp) return;
@@ -157,12 +184,11 @@ __global__ __launch_bounds__(64) void k_v2_prep(const uint8_t* __restrict__ I, f
 }
 
 // ---------------------------------------------------------------------------------------------
-// carry prepass.  grid (nbands, nslices), block 64 (LANE = ROW).
+// carry prepass.  grid (nbands, nslices, nviews), block 64 (LANE = ROW).
 // ---------------------------------------------------------------------------------------------
-constexpr int CB = 16;  // columns per load batch of the carry prepass
-
 template <int MODE>
-__global__ __launch_bounds__(64) void k_v2_carry(Args a) {
+__global__ __launch_bounds__(64) void k_v2_carry(Launch L) {
+    const Args& a = L.v[blockIdx.z];
     const int slice = blockIdx.y;
     const int y = blockIdx.x * 64 + threadIdx.x;
     if (y >= a.h) return;
@@ -203,27 +229,64 @@ __global__ __launch_bounds__(64) void k_v2_carry(Args a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// strip walker.  grid (nstrips, nslices), block 256.
+// strip walker.  grid (nstrips, nslices, nviews), block 256.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int ring_row(int y) { return y % RR; }
 
+// per-pixel arithmetic of the stage on the two box means m0, m1
 template <int MODE>
-__global__ __launch_bounds__(256) void k_v2_walk(Args a) {
-    __shared__ float ring[2][RR][PITCH];
+__device__ __forceinline__ void stage_out(const Args& a, float m0, float m1, float ga, float gb,
+                                          float* __restrict__ dstA, float* __restrict__ dstB,
+                                          size_t T, int xo, int yo) {
+    if (MODE == GUID) {
+        float mm = m0 * m0;          // pixelMultOnGPU(mean, mean) guidedFilter.cu:112
+        float var = m1 - mm;         // pixelSousOnGPU :121
+        float c = (float)(1.0f / ((double)var + a.eps));   // :350
+        dstA[T] = m0;
+        dstB[T] = c;
+        if (a.mean_u8) {             // flToChOnGPU :451-458
+            int ci8 = (int)m0;
+            a.mean_u8[(size_t)yo * a.w + xo] = (ci8 > 255) ? 255 : (uint8_t)ci8;
+        }
+    } else if (MODE == S1) {
+        float mI = ga;
+        float c = gb;
+        float mm = mI * m0;          // compute_ak_and_bk guidedFilter.cu:345-354
+        float ak = 1.0f * (m1 - mm) * c;
+        float mb2 = 1.0f * mI * ak;
+        float bk = 1.0f * m0 - mb2;
+        dstA[T] = ak;
+        dstB[T] = bk;
+    } else {
+        float tq = m0 * ga;          // compute_q guidedFilter.cu:363-369
+        dstA[T] = tq + m1;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_v2_walk(Launch L) {
+    // flat allocation with a small tail pad: the batched phase-B reads of masked-off columns may
+    // run up to PB*NSUB + 2R + 1 floats past the last ring row
+    __shared__ float ring_s[2 * RR * PITCH + 32];
+    float (*ring)[RR][PITCH] = reinterpret_cast<float (*)[RR][PITCH]>(ring_s);
+    const Args& a = L.v[blockIdx.z];
     const int k = blockIdx.x, slice = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int R = a.R, w = a.w, h = a.h, hp = a.hp;
-    const int xs = k * a.ow, cs = xs - (R + 1);
+    const int R = a.R, w = a.w, h = a.h, hp = a.hp, ow = a.ow;
+    const int xs = k * ow, cs = xs - (R + 1);
+    const int dj = 2 * R + 1;
     const size_t plane = (size_t)w * hp;
     const int nbands = (h + BH - 1) / BH;
+    // strips whose every output column has an unclipped window in x take the fast phase B
+    const bool x_interior = (cs >= 0) && (xs + ow - 1 + R <= w - 1);
     // phase C ownership: thread -> (integral, column of the tile)
     const int ci = tid / TW, cj = tid - ci * TW;
     float S = -0.0f;
     const float* __restrict__ meanT = a.meanT;
     const float* __restrict__ cinvT = a.cinvT;
     const float* __restrict__ srcF1 = a.F1;
-    float* __restrict__ dstA = a.dstA;
-    float* __restrict__ dstB = a.dstB;
+    float* __restrict__ dstA = (MODE == GUID) ? a.dstA : a.dstA + (size_t)slice * plane;
+    float* __restrict__ dstB = (MODE == GUID) ? a.dstB : (MODE == S1 ? a.dstB + (size_t)slice * plane : nullptr);
 
     for (int b = 0; b < nbands; ++b) {
         const int y0 = b * BH;
@@ -294,60 +357,87 @@ __global__ __launch_bounds__(256) void k_v2_walk(Args a) {
             const int ych = ymax - (hy ? ymin : -1);
             const int rr1 = ring_row(ymax);
             const int rr0 = ring_row(hy ? ymin : 0);
-            for (int mb = wave; mb < a.ow; mb += NSUB * PB) {
-                // global operands of PB output columns first (one exposed latency per batch)
-                float ga[PB], gb[PB];
+            if (x_interior) {
+                // window width is 2R+1 for every column of the strip: per-lane area and reciprocal
+                const float area = (float)(dj * ych);
+                const float rarea = 1.0f / area;
+                const float* b1 = &ring[0][rr1][0];
+                const float* b0 = &ring[0][rr0][0];
+                for (int mb = wave; mb < ow; mb += NSUB * PB) {
+                    const size_t Tb = (size_t)(xs + mb) * hp + yo;
+                    float ga[PB], gb[PB];
 #pragma unroll
-                for (int t = 0; t < PB; ++t) {
-                    const int m = mb + t * NSUB;
-                    int xo = xs + m;
-                    xo = (m < a.ow && xo < w) ? xo : (w - 1);
-                    const size_t T = (size_t)xo * hp + yo;
-                    if (MODE == S1) { ga[t] = meanT[T]; gb[t] = cinvT[T]; }
-                    if (MODE == S2) { ga[t] = srcF1[(size_t)(xo + 1) * hp + yo]; gb[t] = 0.0f; }
-                    if (MODE == GUID) { ga[t] = 0.0f; gb[t] = 0.0f; }
-                }
+                    for (int t = 0; t < PB; ++t) {
+                        const bool ok = mb + t * NSUB < ow;
+                        const size_t T = ok ? Tb + (size_t)(t * NSUB) * hp : Tb;
+                        ga[t] = 0.0f; gb[t] = 0.0f;
+                        if (MODE == S1) { ga[t] = meanT[T]; gb[t] = cinvT[T]; }
+                        if (MODE == S2) { ga[t] = srcF1[T + hp]; }
+                    }
+                    const float* p1 = b1 + mb;
+                    const float* p0 = b0 + mb;
+                    float s11[PB], s10[PB], s01[PB], s00[PB], u11[PB], u10[PB], u01[PB], u00[PB];
 #pragma unroll
-                for (int t = 0; t < PB; ++t) {
-                    const int m = mb + t * NSUB;
-                    const int xo = xs + m;
-                    if (m < a.ow && xo < w) {
-                        const int xmax = min(w - 1, xo + R);
-                        const int jmax = xmax - cs;
-                        const bool hx = (xo - R - 1) >= 0;
-                        const int jmin = m;  // (xo - R - 1) - cs
-                        const int xcw = xmax - (hx ? xo - R - 1 : -1);
-                        const float area = (float)(xcw * ych);
-                        float val0 = ring[0][rr1][jmax];
-                        float val1 = ring[1][rr1][jmax];
-                        if (hx) { val0 -= ring[0][rr1][jmin]; val1 -= ring[1][rr1][jmin]; }
-                        if (hy) { val0 -= ring[0][rr0][jmax]; val1 -= ring[1][rr0][jmax]; }
-                        if (hx && hy) { val0 += ring[0][rr0][jmin]; val1 += ring[1][rr0][jmin]; }
-                        const float m0 = 1.0f * val0 / area;
-                        const float m1 = 1.0f * val1 / area;
-                        const size_t T = (size_t)xo * hp + yo;
-                        if (MODE == GUID) {
-                            float mm = m0 * m0;          // pixelMultOnGPU(mean, mean) guidedFilter.cu:112
-                            float var = m1 - mm;         // pixelSousOnGPU :121
-                            float c = (float)(1.0f / ((double)var + a.eps));   // :350
-                            dstA[T] = m0;
-                            dstB[T] = c;
-                            if (a.mean_u8) {             // flToChOnGPU :451-458
-                                int ci8 = (int)m0;
-                                a.mean_u8[(size_t)yo * w + xo] = (ci8 > 255) ? 255 : (uint8_t)ci8;
+                    for (int t = 0; t < PB; ++t) {
+                        s10[t] = p1[t * NSUB];            s11[t] = p1[t * NSUB + dj];
+                        s00[t] = p0[t * NSUB];            s01[t] = p0[t * NSUB + dj];
+                        u10[t] = p1[t * NSUB + RR * PITCH];  u11[t] = p1[t * NSUB + dj + RR * PITCH];
+                        u00[t] = p0[t * NSUB + RR * PITCH];  u01[t] = p0[t * NSUB + dj + RR * PITCH];
+                    }
+#pragma unroll
+                    for (int t = 0; t < PB; ++t) {
+                        if (mb + t * NSUB < ow) {
+                            float val0 = s11[t] - s10[t];
+                            float val1 = u11[t] - u10[t];
+                            float t0 = val0 - s01[t], t1 = val1 - u01[t];
+                            val0 = hy ? t0 : val0;  val1 = hy ? t1 : val1;
+                            t0 = val0 + s00[t];     t1 = val1 + u00[t];
+                            val0 = hy ? t0 : val0;  val1 = hy ? t1 : val1;
+                            float m0 = div_small_int(val0, area, rarea);
+                            float m1 = div_small_int(val1, area, rarea);
+                            const bool tiny = (fabsf(val0) < 0x1p-100f) || (fabsf(val1) < 0x1p-100f);
+                            if (__any(tiny)) {
+                                m0 = 1.0f * val0 / area;
+                                m1 = 1.0f * val1 / area;
                             }
-                        } else if (MODE == S1) {
-                            float mI = ga[t];
-                            float c = gb[t];
-                            float mm = mI * m0;          // compute_ak_and_bk guidedFilter.cu:345-354
-                            float ak = 1.0f * (m1 - mm) * c;
-                            float mb2 = 1.0f * mI * ak;
-                            float bk = 1.0f * m0 - mb2;
-                            dstA[(size_t)slice * plane + T] = ak;
-                            dstB[(size_t)slice * plane + T] = bk;
-                        } else {
-                            float tq = m0 * ga[t];       // compute_q guidedFilter.cu:363-369
-                            dstA[(size_t)slice * plane + T] = tq + m1;
+                            stage_out<MODE>(a, m0, m1, ga[t], gb[t], dstA, dstB,
+                                            Tb + (size_t)(t * NSUB) * hp, xs + mb + t * NSUB, yo);
+                        }
+                    }
+                }
+            } else {
+                for (int mb = wave; mb < ow; mb += NSUB * PB) {
+                    float ga[PB], gb[PB];
+#pragma unroll
+                    for (int t = 0; t < PB; ++t) {
+                        const int m = mb + t * NSUB;
+                        int xo = xs + m;
+                        xo = (m < ow && xo < w) ? xo : (w - 1);
+                        const size_t T = (size_t)xo * hp + yo;
+                        ga[t] = 0.0f; gb[t] = 0.0f;
+                        if (MODE == S1) { ga[t] = meanT[T]; gb[t] = cinvT[T]; }
+                        if (MODE == S2) { ga[t] = srcF1[T + hp]; }
+                    }
+#pragma unroll
+                    for (int t = 0; t < PB; ++t) {
+                        const int m = mb + t * NSUB;
+                        const int xo = xs + m;
+                        if (m < ow && xo < w) {
+                            const int xmax = min(w - 1, xo + R);
+                            const int jmax = xmax - cs;
+                            const bool hx = (xo - R - 1) >= 0;
+                            const int jmin = m;  // (xo - R - 1) - cs
+                            const int xcw = xmax - (hx ? xo - R - 1 : -1);
+                            const float area = (float)(xcw * ych);
+                            float val0 = ring[0][rr1][jmax];
+                            float val1 = ring[1][rr1][jmax];
+                            if (hx) { val0 -= ring[0][rr1][jmin]; val1 -= ring[1][rr1][jmin]; }
+                            if (hy) { val0 -= ring[0][rr0][jmax]; val1 -= ring[1][rr0][jmax]; }
+                            if (hx && hy) { val0 += ring[0][rr0][jmin]; val1 += ring[1][rr0][jmin]; }
+                            const float m0 = 1.0f * val0 / area;
+                            const float m1 = 1.0f * val1 / area;
+                            stage_out<MODE>(a, m0, m1, ga[t], gb[t], dstA, dstB,
+                                            (size_t)xo * hp + yo, xo, yo);
                         }
                     }
                 }
@@ -359,17 +449,35 @@ __global__ __launch_bounds__(256) void k_v2_walk(Args a) {
 
 // ---------------------------------------------------------------------------------------------
 // WTA over the chunk's q planes (transposed).  One lane per pixel, y fastest.
+// grid (ceil(h/64), w, nviews)
 // ---------------------------------------------------------------------------------------------
-__global__ void k_v2_wta(const float* __restrict__ qT, uint64_t* __restrict__ keys, int w, int h,
-                         int hp, int count, int slice0) {
-    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+struct WtaArgs {
+    const float* qT[2];
+    uint64_t* keys[2];
+};
+
+__global__ __launch_bounds__(64) void k_v2_wta(WtaArgs wa, int w, int h, int hp, int count,
+                                               int slice0) {
+    const int y = blockIdx.x * 64 + threadIdx.x;
     const int x = blockIdx.y;
     if (y >= h) return;
     const size_t plane = (size_t)w * hp;
-    const float* q = qT + (size_t)x * hp + y;
+    const float* __restrict__ q = wa.qT[blockIdx.z] + (size_t)x * hp + y;
+    uint64_t* keys = wa.keys[blockIdx.z];
     const size_t id = (size_t)y * w + x;
     uint64_t key = keys[id];
-    for (int z = 0; z < count; ++z) {
+    int z = 0;
+    for (; z + 8 <= count; z += 8) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = q[(size_t)(z + t) * plane];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            uint64_t kk = pack_key(v[t], (uint32_t)(slice0 + z + t));
+            key = kk < key ? kk : key;
+        }
+    }
+    for (; z < count; ++z) {
         uint64_t kk = pack_key(q[(size_t)z * plane], (uint32_t)(slice0 + z));
         key = kk < key ? kk : key;
     }
@@ -423,105 +531,158 @@ static V2Layout v2_layout(int w, int h, int R) {
 
 bool v2_supported(const smx_params* p) { return p->radius >= 0 && p->radius <= v2::RMAX; }
 
+// bytes for ONE view with `nslices` slices in flight
 size_t v2_workspace_bytes(int w, int h, int R, int nslices) {
-    if (R < 0 || R > v2::RMAX) R = v2::RMAX;
-    V2Layout L = v2_layout(w, h, R);
-    size_t fl = 4 * L.padded_plane + 2 * L.plane + L.carry_slice +
-                (size_t)nslices * (3 * L.plane + L.carry_slice);
-    return fl * sizeof(float) + 16 * 256;
+    (void)R;  // the largest radius has the narrowest strips, i.e. the most carry segments
+    V2Layout L9 = v2_layout(w, h, v2::RMAX);
+    size_t fl = 4 * L9.padded_plane + 2 * L9.plane + L9.carry_slice +
+                (size_t)nslices * (3 * L9.plane + L9.carry_slice);
+    return fl * sizeof(float) + 24 * 256;
+}
+
+// side stream used to overlap the (latency-bound, single-slice) guidance stage with the stage-1
+// carry prepass; fork/join with events so the caller's stream semantics are preserved
+static thread_local hipStream_t g_side = nullptr;
+static thread_local hipEvent_t g_fork = nullptr, g_join = nullptr;
+
+static int ensure_side_stream() {
+    if (!g_side) {
+        SMX_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+        SMX_HIP(hipEventCreateWithFlags(&g_fork, hipEventDisableTiming));
+        SMX_HIP(hipEventCreateWithFlags(&g_join, hipEventDisableTiming));
+    }
+    return SMX_OK;
 }
 
 template <int MODE>
-static int v2_run_stage(const v2::Args& a, int nslices, hipStream_t st) {
-    if (nslices <= 0) return SMX_OK;
-    const int nbands = (a.h + 63) / 64;
-    hipLaunchKernelGGL(v2::k_v2_carry<MODE>, dim3(nbands, nslices), dim3(64), 0, st, a);
-    SMX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(v2::k_v2_walk<MODE>, dim3(a.nstrips, nslices), dim3(256), 0, st, a);
+static int launch_carry(const v2::Launch& L, int nslices, int nviews, hipStream_t st) {
+    const v2::Args& a = L.v[0];
+    hipLaunchKernelGGL(v2::k_v2_carry<MODE>, dim3((a.h + 63) / 64, nslices, nviews), dim3(64), 0, st, L);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
 
-// Aggregation + WTA of slices [s_begin, s_end) of one view with the cost built on the fly.
-int aggregate_v2(const smx_params* p, const uint8_t* d_guide, const uint8_t* d_other, int w, int h,
-                 int dmin, int s_begin, int s_end, uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg,
-                 void* d_ws, size_t ws_bytes, hipStream_t st, int* launches) {
+template <int MODE>
+static int launch_walk(const v2::Launch& L, int nslices, int nviews, hipStream_t st) {
+    const v2::Args& a = L.v[0];
+    hipLaunchKernelGGL(v2::k_v2_walk<MODE>, dim3(a.nstrips, nslices, nviews), dim3(256), 0, st, L);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+// Aggregation + WTA of slices [s_begin, s_end) of `nviews` (1 or 2) views with the cost built on
+// the fly.  View v uses d_img[v] as guidance and d_img[v ^ 1] (nviews == 2) or d_other as the
+// matching image; keys/mean/agg pointers are per view.
+int aggregate_v2(const smx_params* p, int nviews, const uint8_t* const* d_guide,
+                 const uint8_t* const* d_other, int w, int h, const int* dmin, int s_begin, int s_end,
+                 uint64_t* const* d_keys, uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws,
+                 size_t ws_bytes, hipStream_t st, int* launches) {
     const int R = p->radius;
     V2Layout L = v2_layout(w, h, R);
     char* base = (char*)align_up((size_t)d_ws, 256);
-    size_t avail = ws_bytes - (size_t)(base - (char*)d_ws);
+    size_t avail = ws_bytes > (size_t)(base - (char*)d_ws) ? ws_bytes - (size_t)(base - (char*)d_ws) : 0;
+    bool oom = false;
     auto carve = [&](size_t nfloat) {
         float* r = (float*)base;
         size_t b = align_up(nfloat * sizeof(float), 256);
+        if (b > avail) { oom = true; b = avail; }
         base += b;
-        avail = avail >= b ? avail - b : 0;
+        avail -= b;
         return r;
     };
-    const size_t fixed = 4 * align_up(L.padded_plane * 4, 256) + 2 * align_up(L.plane * 4, 256) +
-                         align_up(L.carry_slice * 4, 256);
     const size_t per_slice = (3 * L.plane + L.carry_slice) * sizeof(float);
-    if (avail < fixed + per_slice + 4 * 256)
-        return fail(SMX_E_WS, "aggregate_v2: workspace %zu B too small (need >= %zu B)", ws_bytes,
-                    v2_workspace_bytes(w, h, R, 1));
-    float* F1 = carve(L.padded_plane);
-    float* G1 = carve(L.padded_plane);
-    float* F2 = carve(L.padded_plane);
-    float* G2 = carve(L.padded_plane);
-    float* meanT = carve(L.plane);
-    float* cinvT = carve(L.plane);
-    float* gcarry = carve(L.carry_slice);
+    // fixed planes: the two images' F/G are shared by both views of a pair
+    const int nimg = 2;
+    float *F[2], *G[2], *meanT[2], *cinvT[2], *gcarry[2];
+    for (int i = 0; i < nimg; ++i) { F[i] = carve(L.padded_plane); G[i] = carve(L.padded_plane); }
+    for (int v = 0; v < nviews; ++v) {
+        meanT[v] = carve(L.plane); cinvT[v] = carve(L.plane); gcarry[v] = carve(L.carry_slice);
+    }
     const int total = s_end - s_begin;
-    size_t fit = (avail - 4 * 256) / per_slice;
+    size_t fit = avail > 8 * 256 ? (avail - 8 * 256) / (per_slice * nviews) : 0;
+    if (oom || fit < 1)
+        return fail(SMX_E_WS, "aggregate_v2: workspace %zu B too small (need >= %zu B per view)",
+                    ws_bytes, v2_workspace_bytes(w, h, R, 1));
     int chunk = fit > (size_t)total ? total : (int)fit;
     if (chunk < 1) chunk = 1;
-    float* aT = carve((size_t)chunk * L.plane);
-    float* bT = carve((size_t)chunk * L.plane);
-    float* qT = carve((size_t)chunk * L.plane);
-    float* carry = carve((size_t)chunk * L.carry_slice);
+    float *aT[2], *bT[2], *qT[2], *carry[2];
+    for (int v = 0; v < nviews; ++v) {
+        aT[v] = carve((size_t)chunk * L.plane);
+        bT[v] = carve((size_t)chunk * L.plane);
+        qT[v] = carve((size_t)chunk * L.plane);
+        carry[v] = carve((size_t)chunk * L.carry_slice);
+    }
+    if (oom) return fail(SMX_E_WS, "aggregate_v2: workspace carve overflow");
 
-    int nl = 0;
-    dim3 pgrid(L.hp / 64, w + 2);
-    hipLaunchKernelGGL(v2::k_v2_prep, pgrid, dim3(64), 0, st, d_guide, F1, G1, w, h, L.hp);
+    int nl = 0, rc;
+    // image 0 = guide of view 0; image 1 = the other image (guide of view 1 in a pair)
+    v2::PrepArgs pa;
+    pa.I[0] = d_guide[0]; pa.I[1] = nviews == 2 ? d_guide[1] : d_other[0];
+    pa.F[0] = F[0]; pa.F[1] = F[1]; pa.G[0] = G[0]; pa.G[1] = G[1];
+    hipLaunchKernelGGL(v2::k_v2_prep, dim3(L.hp / 64, w + 2, 2), dim3(64), 0, st, pa, w, h, L.hp);
     SMX_HIP(hipGetLastError());
-    hipLaunchKernelGGL(v2::k_v2_prep, pgrid, dim3(64), 0, st, d_other, F2, G2, w, h, L.hp);
-    SMX_HIP(hipGetLastError());
-    nl += 2;
+    ++nl;
 
-    v2::Args a;
-    memset(&a, 0, sizeof(a));
-    a.w = w; a.h = h; a.hp = L.hp; a.R = R; a.ow = L.ow; a.nstrips = L.nstrips; a.nsegs = L.nsegs;
-    a.F1 = F1; a.G1 = G1; a.F2 = F2; a.G2 = G2;
-    a.cc = make_cost_const(p);
-    a.eps = p->eps;
-    int rc;
-    // guidance statistics
+    v2::Launch base_l;
+    memset(&base_l, 0, sizeof(base_l));
+    for (int v = 0; v < nviews; ++v) {
+        v2::Args& a = base_l.v[v];
+        a.w = w; a.h = h; a.hp = L.hp; a.R = R; a.ow = L.ow; a.nstrips = L.nstrips; a.nsegs = L.nsegs;
+        a.F1 = F[v]; a.G1 = G[v]; a.F2 = F[v ^ 1]; a.G2 = G[v ^ 1];
+        a.cc = make_cost_const(p);
+        a.eps = p->eps;
+    }
+    // ---- guidance statistics on the side stream, overlapped with the first stage-1 carry prepass
+    if ((rc = ensure_side_stream())) return rc;
+    SMX_HIP(hipEventRecord(g_fork, st));
+    SMX_HIP(hipStreamWaitEvent(g_side, g_fork, 0));
     {
-        v2::Args g = a;
-        g.dstA = meanT; g.dstB = cinvT; g.mean_u8 = d_mean_u8; g.carry = gcarry;
-        if ((rc = v2_run_stage<v2::GUID>(g, 1, st))) return rc;
+        v2::Launch g = base_l;
+        for (int v = 0; v < nviews; ++v) {
+            g.v[v].dstA = meanT[v]; g.v[v].dstB = cinvT[v];
+            g.v[v].mean_u8 = d_mean_u8 ? d_mean_u8[v] : nullptr;
+            g.v[v].carry = gcarry[v];
+        }
+        if ((rc = launch_carry<v2::GUID>(g, 1, nviews, g_side))) return rc;
+        if ((rc = launch_walk<v2::GUID>(g, 1, nviews, g_side))) return rc;
         nl += 2;
     }
-    a.meanT = meanT; a.cinvT = cinvT;
+    SMX_HIP(hipEventRecord(g_join, g_side));
+    bool joined = false;
+    for (int v = 0; v < nviews; ++v) { base_l.v[v].meanT = meanT[v]; base_l.v[v].cinvT = cinvT[v]; }
+
     for (int s0 = s_begin; s0 < s_end; s0 += chunk) {
         const int cnt = (s_end - s0) < chunk ? (s_end - s0) : chunk;
-        v2::Args s1 = a;
-        s1.d0 = dmin + s0; s1.dstA = aT; s1.dstB = bT; s1.carry = carry;
-        if ((rc = v2_run_stage<v2::S1>(s1, cnt, st))) return rc;
-        v2::Args s2 = a;
-        s2.srcA = aT; s2.srcB = bT; s2.dstA = qT; s2.carry = carry;
-        if ((rc = v2_run_stage<v2::S2>(s2, cnt, st))) return rc;
-        hipLaunchKernelGGL(v2::k_v2_wta, dim3(cdivu(h, 64), w), dim3(64), 0, st, qT, d_keys, w, h,
-                           L.hp, cnt, s0);
+        v2::Launch s1 = base_l, s2 = base_l;
+        for (int v = 0; v < nviews; ++v) {
+            s1.v[v].d0 = dmin[v] + s0; s1.v[v].dstA = aT[v]; s1.v[v].dstB = bT[v]; s1.v[v].carry = carry[v];
+            s2.v[v].srcA = aT[v]; s2.v[v].srcB = bT[v]; s2.v[v].dstA = qT[v]; s2.v[v].carry = carry[v];
+        }
+        if ((rc = launch_carry<v2::S1>(s1, cnt, nviews, st))) return rc;
+        if (!joined) {
+            SMX_HIP(hipStreamWaitEvent(st, g_join, 0));
+            joined = true;
+        }
+        if ((rc = launch_walk<v2::S1>(s1, cnt, nviews, st))) return rc;
+        if ((rc = launch_carry<v2::S2>(s2, cnt, nviews, st))) return rc;
+        if ((rc = launch_walk<v2::S2>(s2, cnt, nviews, st))) return rc;
+        v2::WtaArgs wa;
+        for (int v = 0; v < 2; ++v) { wa.qT[v] = qT[v < nviews ? v : 0]; wa.keys[v] = d_keys[v < nviews ? v : 0]; }
+        hipLaunchKernelGGL(v2::k_v2_wta, dim3(cdivu(h, 64), w, nviews), dim3(64), 0, st, wa, w, h, L.hp,
+                           cnt, s0);
         SMX_HIP(hipGetLastError());
         nl += 5;
-        if (d_agg) {
-            dim3 tg(cdivu(w, 32), cdivu(h, 32), cnt);
-            hipLaunchKernelGGL(v2::k_v2_untranspose, tg, dim3(256), 0, st, qT,
-                               d_agg + (size_t)(s0 - s_begin) * w * h, w, h, L.hp);
-            SMX_HIP(hipGetLastError());
-            ++nl;
+        for (int v = 0; v < nviews; ++v) {
+            if (d_agg && d_agg[v]) {
+                dim3 tg(cdivu(w, 32), cdivu(h, 32), cnt);
+                hipLaunchKernelGGL(v2::k_v2_untranspose, tg, dim3(256), 0, st, qT[v],
+                                   d_agg[v] + (size_t)(s0 - s_begin) * w * h, w, h, L.hp);
+                SMX_HIP(hipGetLastError());
+                ++nl;
+            }
         }
     }
+    if (!joined) SMX_HIP(hipStreamWaitEvent(st, g_join, 0));
     if (launches) *launches = nl;
     return SMX_OK;
 }

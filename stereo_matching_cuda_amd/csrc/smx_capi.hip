@@ -20,9 +20,10 @@ static thread_local int g_last_path = 0;
 // smx_agg_v2.hip
 bool v2_supported(const smx_params* p);
 size_t v2_workspace_bytes(int w, int h, int R, int nslices);
-int aggregate_v2(const smx_params* p, const uint8_t* d_guide, const uint8_t* d_other, int w, int h,
-                 int dmin, int s_begin, int s_end, uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg,
-                 void* d_ws, size_t ws_bytes, hipStream_t st, int* launches);
+int aggregate_v2(const smx_params* p, int nviews, const uint8_t* const* d_guide,
+                 const uint8_t* const* d_other, int w, int h, const int* dmin, int s_begin, int s_end,
+                 uint64_t* const* d_keys, uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws,
+                 size_t ws_bytes, hipStream_t st, int* launches);
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -179,8 +180,8 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
     if (can_v2 && g_agg_path != 1) {
         g_launches = 0;
         if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
-        int rc2 = aggregate_v2(p, d_guide, d_other, w, h, dmin, s_begin, s_end, d_keys, d_mean_u8,
-                               d_agg, d_workspace, workspace_bytes, st, &g_launches);
+        int rc2 = aggregate_v2(p, 1, &d_guide, &d_other, w, h, &dmin, s_begin, s_end, &d_keys,
+                               &d_mean_u8, &d_agg, d_workspace, workspace_bytes, st, &g_launches);
         if (rc2) return rc2;
         if (g_timing) {
             SMX_HIP(hipEventRecord(g_ev1, st));
@@ -247,6 +248,45 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
         g_ev_valid = true;
     }
     return SMX_OK;
+}
+
+int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const uint8_t* d_right,
+                               int w, int h, int dminl, int dminr, int s_begin, int s_end,
+                               uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
+                               size_t workspace_bytes, void* stream) {
+    SMX_ARG(p && d_left && d_right && d_keys && d_workspace);
+    SMX_ARG(w >= 2 && h >= 1 && s_begin >= 0 && s_end >= s_begin && p->radius >= 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)w * h;
+    const int64_t vol = n * (s_end - s_begin);
+    if (v2_supported(p) && g_agg_path != 1) {
+        const uint8_t* guide[2] = {d_left, d_right};
+        const uint8_t* other[2] = {d_right, d_left};
+        const int dmin[2] = {dminl, dminr};
+        uint64_t* keys[2] = {d_keys, d_keys + n};
+        uint8_t* mean[2] = {d_mean_u8, d_mean_u8 ? d_mean_u8 + n : nullptr};
+        float* agg[2] = {d_agg, d_agg ? d_agg + vol : nullptr};
+        g_launches = 0;
+        if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
+        int rc2 = aggregate_v2(p, 2, guide, other, w, h, dmin, s_begin, s_end, keys,
+                               d_mean_u8 ? mean : nullptr, d_agg ? agg : nullptr, d_workspace,
+                               workspace_bytes, st, &g_launches);
+        if (rc2) return rc2;
+        if (g_timing) {
+            SMX_HIP(hipEventRecord(g_ev1, st));
+            g_ev_valid = true;
+        }
+        g_last_path = 2;
+        return SMX_OK;
+    }
+    if (g_agg_path == 2)
+        return fail(SMX_E_ARG, "smx_dev_aggregate_wta_pair: fused path forced but radius > 9");
+    int rc = smx_dev_aggregate_wta(p, d_left, d_right, nullptr, w, h, dminl, s_begin, s_end, d_keys,
+                                   d_mean_u8, d_agg, d_workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    return smx_dev_aggregate_wta(p, d_right, d_left, nullptr, w, h, dminr, s_begin, s_end, d_keys + n,
+                                 d_mean_u8 ? d_mean_u8 + n : nullptr, d_agg ? d_agg + vol : nullptr,
+                                 d_workspace, workspace_bytes, stream);
 }
 
 /* ------------------------------------------------------------------------------------------

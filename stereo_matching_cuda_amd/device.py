@@ -40,10 +40,11 @@ class PairPipeline:
         self.params = params if params is not None else _lib.default_params()
         local = max(1, self.s_end - self.s_begin)
         sif = local if slices_in_flight is None else max(1, min(local, int(slices_in_flight)))
-        while sif > 1 and self.lib.smx_agg_workspace_bytes(self.w, self.h, sif) > max_ws_bytes:
+        while sif > 1 and 2 * self.lib.smx_agg_workspace_bytes(self.w, self.h, sif) > max_ws_bytes:
             sif = (sif + 1) // 2
         self.slices_in_flight = sif
-        self.ws_bytes = int(self.lib.smx_agg_workspace_bytes(self.w, self.h, sif))
+        # pair calls (both views per launch) need twice the single-view workspace
+        self.ws_bytes = 2 * int(self.lib.smx_agg_workspace_bytes(self.w, self.h, sif))
         dev = self.device
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         # keys[0] = left view, keys[1] = right view: one buffer so the shard merge is ONE all-reduce
@@ -61,8 +62,18 @@ class PairPipeline:
         """Cost build (fused unless cost_* given) + guided-filter aggregation + running WTA of this
         rank's slices, both views.  Leaves packed keys in self.keys."""
         self.init_keys()
-        self.aggregate_view(0, gray_l, gray_r, cost_l)
-        self.aggregate_view(1, gray_r, gray_l, cost_r)
+        if cost_l is None and cost_r is None:
+            self.aggregate_pair(gray_l, gray_r)
+        else:
+            self.aggregate_view(0, gray_l, gray_r, cost_l)
+            self.aggregate_view(1, gray_r, gray_l, cost_r)
+
+    def aggregate_pair(self, gray_l, gray_r):
+        """Both views per kernel launch (smx_dev_aggregate_wta_pair)."""
+        L, P, st = self.lib, C.byref(self.params), _stream()
+        _lib.check(L.smx_dev_aggregate_wta_pair(
+            P, _dp(gray_l), _dp(gray_r), self.w, self.h, self.dminl, self.dminr, self.s_begin,
+            self.s_end, _dp(self.keys), _dp(self.mean), _dp(self.agg), _dp(self.ws), self.ws_bytes, st))
 
     def init_keys(self):
         _lib.check(self.lib.smx_dev_init_keys(_dp(self.keys), 2 * self.n, _stream()))
