@@ -53,10 +53,58 @@ static_assert(SUBW % RBATCH == 0 && 2 * TW <= 256, "tile geometry");
 
 enum Mode { GUID = 0, S1 = 1, S2 = 2 };
 
+// (pixel value, x-derivative) packed as two IEEE halves: values are integers in [0, 255] and
+// multiples of 0.5 in [-127.5, 127.5], both exact in fp16; the sentinel 60000 saturates both
+// truncated cost terms like the reference's out-of-range branch (costVolume.cu:184).
+typedef _Float16 fg_t __attribute__((ext_vector_type(2)));
+
+// Addressing idiom of this file: every global access is  uniform_pointer + 32-bit lane BYTE offset
+// so the compiler keeps the pointer in SGPRs (global_load ... v_off, s[base:base+1]) instead of
+// building a 64-bit VGPR address per access (two VGPRs per outstanding load).  The offset must be
+// a 32-bit value that is zero-extended as is -- `ptr[lane]` (zext then shift) does not match.
+// Band-blocked transposed plane layout ("[band][x][64 rows]"): element (x, y) of a plane that is
+// Wp columns wide lives at  ((y >> 6) * Wp + x) * 64 + (y & 63).  A wave (LANE = ROW, 64 rows of one
+// band) touches 256 contiguous bytes per column and consecutive columns are adjacent, so a band
+// tile of a strip is one contiguous run in HBM.  bcol() is the wave-uniform part, blane() the
+// per-lane part (fits 32 bits: a plane is < 4 GiB).
+__host__ __device__ __forceinline__ size_t bcol(int x) { return (size_t)x * 64; }
+__host__ __device__ __forceinline__ unsigned blane(int y, int Wp) {
+    return ((unsigned)(y >> 6) * (unsigned)Wp) * 64u + (unsigned)(y & 63);
+}
+
+template <class T>
+__device__ __forceinline__ T ldl(const T* ubase, unsigned boff) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(ubase) + boff);
+}
+template <class T>
+__device__ __forceinline__ void stl(T* ubase, unsigned boff, T v) {
+    *reinterpret_cast<T*>(reinterpret_cast<char*>(ubase) + boff) = v;
+}
+
+// Buffer-descriptor accesses for the walker: 128-bit descriptor in SGPRs (built from kernel
+// arguments and blockIdx only, so it is provably wave-uniform), per-lane byte offset in ONE VGPR
+// that is constant across the columns of a band, per-column byte offset in an SGPR / immediate.
+// No per-access VALU address arithmetic; out-of-range accesses are dropped by the hardware.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t mk_rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0,
+                                             (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes),
+                                             0x00020000);
+}
+__device__ __forceinline__ uint32_t bld(rsrc_t r, unsigned voff, unsigned soff) {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ float bldf(rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bstf(rsrc_t r, unsigned voff, unsigned soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, 0);
+}
+
 struct Args {
     int w, h, hp, R, ow, nstrips, nsegs;
-    const float* F1; const float* G1;   // this view: value / gradient, padded transposed planes
-    const float* F2; const float* G2;   // other view (S1 only)
+    const fg_t* FG1;                    // this view: (value, x-gradient) as half2, padded transposed
+    const fg_t* FG2;                    // other view (S1 only)
     const float* meanT; const float* cinvT;  // guidance statistics [x*hp + y] (S1 reads, GUID writes)
     const float* srcA; const float* srcB;    // S2 sources: aT, bT [slice][x*hp + y]
     float* dstA; float* dstB;           // GUID: meanT, cinvT; S1: aT, bT; S2: qT (dstB unused)
@@ -86,21 +134,36 @@ __device__ __forceinline__ float div_small_int(float x, float d, float r) {
     return __builtin_fmaf(e, r, q);
 }
 
+// p = (1-alpha)*min(|I1 - I2|, 7) + alpha*min(|g1 - g2|, 2) and I1*p  (costVolume.cu:187,
+// guidedFilter.cu:209).  The halves convert exactly, so the f32 operations equal the reference's.
+__device__ __forceinline__ void cost_pair(fg_t q1, fg_t q2, const CostConst& cc, float& p, float& ip) {
+    const float a1 = (float)q1.x, b1 = (float)q1.y, a2 = (float)q2.x, b2 = (float)q2.y;
+    float t1 = fabsf(a1 - a2);
+    float t2 = fabsf(b1 - b2);
+    float m1 = t1 < cc.th_color ? t1 : cc.th_color;
+    float m2 = t2 < cc.th_grad ? t2 : cc.th_grad;
+    float x = cc.oma * m1;
+    float z = cc.alpha * m2;
+    p = x + z;
+    ip = a1 * p;
+}
+
 // The two scanned quantities of NB consecutive columns of row y (LANE = ROW; every load is a 256-B
 // coalesced row of a transposed plane).  All global loads of a batch are issued before the first
 // use, so one batch exposes one memory latency instead of NB.  Columns outside [0, w) are clamped
 // (their values are never accumulated).
 template <int MODE>
 struct Source {
-    const float *f1, *g1, *f2, *g2, *sa, *sb;
+    const fg_t *fg1, *fg2;
+    const float *sa, *sb;
     int hp, w, d;
     CostConst cc;
     __device__ __forceinline__ Source(const Args& a, int slice, int y) {
         hp = a.hp; w = a.w; d = a.d0 + slice; cc = a.cc;
-        f1 = a.F1 + y; g1 = a.G1 + y; f2 = a.F2 + y; g2 = a.G2 + y;
+        fg1 = a.FG1 + blane(y, a.w + 2); fg2 = a.FG2 + blane(y, a.w + 2);
         const size_t plane = (size_t)a.w * a.hp;
-        sa = MODE == S2 ? a.srcA + (size_t)slice * plane + y : nullptr;
-        sb = MODE == S2 ? a.srcB + (size_t)slice * plane + y : nullptr;
+        sa = MODE == S2 ? a.srcA + (size_t)slice * plane + blane(y, a.w) : nullptr;
+        sb = MODE == S2 ? a.srcB + (size_t)slice * plane + blane(y, a.w) : nullptr;
     }
     template <int NB>
     __device__ __forceinline__ void load(int c0, float (&v0)[NB], float (&v1)[NB]) const {
@@ -109,39 +172,29 @@ struct Source {
             for (int t = 0; t < NB; ++t) {
                 int c = c0 + t;
                 c = c < 0 ? 0 : (c >= w ? w - 1 : c);
-                v0[t] = f1[(size_t)(c + 1) * hp];      // chToFlOnGPU
+                v0[t] = (float)fg1[bcol(c + 1)].x;      // chToFlOnGPU
             }
 #pragma unroll
             for (int t = 0; t < NB; ++t) v1[t] = v0[t] * v0[t];   // pixelMultOnGPU(d_im, d_im)
         } else if (MODE == S1) {
-            float a2[NB], b1[NB], b2[NB];
+            fg_t p1[NB], p2[NB];
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
                 int c = c0 + t;
                 c = c < 0 ? 0 : (c >= w ? w - 1 : c);
                 int xx = c + d;
                 xx = xx < -1 ? -1 : (xx > w ? w : xx);  // sentinel columns at -1 and w
-                const size_t o1 = (size_t)(c + 1) * hp, o2 = (size_t)(xx + 1) * hp;
-                v1[t] = f1[o1]; b1[t] = g1[o1]; a2[t] = f2[o2]; b2[t] = g2[o2];
+                p1[t] = fg1[bcol(c + 1)];
+                p2[t] = fg2[bcol(xx + 1)];
             }
 #pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                float t1 = fabsf(v1[t] - a2[t]);
-                float t2 = fabsf(b1[t] - b2[t]);
-                float m1 = t1 < cc.th_color ? t1 : cc.th_color;
-                float m2 = t2 < cc.th_grad ? t2 : cc.th_grad;
-                float x = cc.oma * m1;
-                float z = cc.alpha * m2;
-                float p = x + z;        // costVolume.cu:187
-                v0[t] = p;
-                v1[t] = v1[t] * p;      // pixelMultOnGPU(d_im, d_pki) guidedFilter.cu:209
-            }
+            for (int t = 0; t < NB; ++t) cost_pair(p1[t], p2[t], cc, v0[t], v1[t]);
         } else {
 #pragma unroll
             for (int t = 0; t < NB; ++t) {
                 int c = c0 + t;
                 c = c < 0 ? 0 : (c >= w ? w - 1 : c);
-                const size_t o = (size_t)c * hp;
+                const size_t o = bcol(c);
                 v0[t] = sa[o];
                 v1[t] = sb[o];
             }
@@ -155,20 +208,18 @@ struct Source {
 // ---------------------------------------------------------------------------------------------
 struct PrepArgs {
     const uint8_t* I[2];
-    float* F[2];
-    float* G[2];
+    fg_t* FG[2];
 };
 
 __global__ __launch_bounds__(64) void k_v2_prep(PrepArgs pa, int w, int h, int hp) {
     const uint8_t* __restrict__ I = pa.I[blockIdx.z];
-    float* __restrict__ F = pa.F[blockIdx.z];
-    float* __restrict__ G = pa.G[blockIdx.z];
+    fg_t* __restrict__ FG = pa.FG[blockIdx.z];
     const int y = blockIdx.x * 64 + threadIdx.x;
     const int x = (int)blockIdx.y - 1;
     if (y >= hp) return;
     float f = 0.0f, g = 0.0f;
     if (x < 0 || x >= w) {
-        f = 1e9f; g = 1e9f;
+        f = 60000.0f; g = 60000.0f;
     } else if (y < h) {
         const uint8_t* row = I + (size_t)y * w;
         f = 1.0f * (float)(int)row[x];
@@ -178,9 +229,10 @@ __global__ __launch_bounds__(64) void k_v2_prep(PrepArgs pa, int w, int h, int h
         else                         { c1 = row[x + 1]; c2 = row[x];     }
         g = 1.0f * (float)(c2 - c1) / 2;
     }
-    const size_t o = (size_t)(x + 1) * hp + y;
-    F[o] = f;
-    G[o] = g;
+    fg_t v;
+    v.x = (_Float16)f;
+    v.y = (_Float16)g;
+    FG[blane(y, w + 2) + bcol(x + 1)] = v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -233,17 +285,26 @@ __global__ __launch_bounds__(64) void k_v2_carry(Launch L) {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int ring_row(int y) { return y % RR; }
 
-// per-pixel arithmetic of the stage on the two box means m0, m1
+// descriptors of the planes a walker workgroup touches (all wave-uniform)
+struct Planes {
+    rsrc_t fg1, fg2;        // padded image planes
+    rsrc_t mean, cinv;      // guidance statistics (S1 reads)
+    rsrc_t srcA, srcB;      // S2 sources (this slice's plane)
+    rsrc_t dstA, dstB;      // outputs (this slice's plane)
+    rsrc_t car0, car1;      // this wave's carry columns
+};
+
+// per-pixel arithmetic of the stage on the two box means m0, m1; the outputs go to column xo
+// (byte offset cob = xo * 256) at the lane's row (byte offset yb) of the slice's output planes
 template <int MODE>
-__device__ __forceinline__ void stage_out(const Args& a, float m0, float m1, float ga, float gb,
-                                          float* __restrict__ dstA, float* __restrict__ dstB,
-                                          size_t T, int xo, int yo) {
+__device__ __forceinline__ void stage_out(const Args& a, const Planes& P, float m0, float m1, float ga,
+                                          float gb, int xo, unsigned yo, unsigned yb, unsigned cob) {
     if (MODE == GUID) {
         float mm = m0 * m0;          // pixelMultOnGPU(mean, mean) guidedFilter.cu:112
         float var = m1 - mm;         // pixelSousOnGPU :121
         float c = (float)(1.0f / ((double)var + a.eps));   // :350
-        dstA[T] = m0;
-        dstB[T] = c;
+        bstf(P.dstA, yb, cob, m0);
+        bstf(P.dstB, yb, cob, c);
         if (a.mean_u8) {             // flToChOnGPU :451-458
             int ci8 = (int)m0;
             a.mean_u8[(size_t)yo * a.w + xo] = (ci8 > 255) ? 255 : (uint8_t)ci8;
@@ -255,67 +316,159 @@ __device__ __forceinline__ void stage_out(const Args& a, float m0, float m1, flo
         float ak = 1.0f * (m1 - mm) * c;
         float mb2 = 1.0f * mI * ak;
         float bk = 1.0f * m0 - mb2;
-        dstA[T] = ak;
-        dstB[T] = bk;
+        bstf(P.dstA, yb, cob, ak);
+        bstf(P.dstB, yb, cob, bk);
     } else {
         float tq = m0 * ga;          // compute_q guidedFilter.cu:363-369
-        dstA[T] = tq + m1;
+        bstf(P.dstA, yb, cob, tq + m1);
+    }
+}
+
+constexpr int NCB = (TW - 1 + NSUB - 1) / NSUB;   // max output columns per wave (R = 0): 26
+constexpr int NBATCH = (NCB + PB - 1) / PB;         // 7
+
+// raw operands of one sub-strip row (SUBW columns), loaded one band ahead of their use:
+// one dword per column and plane (S1: two half2 planes; S2: a and b; GUID: one half2 plane)
+template <int MODE>
+struct RawRow {
+    uint32_t u[MODE == GUID ? 1 : 2][SUBW];
+};
+
+template <int MODE>
+__device__ __forceinline__ void raw_load(const Planes& P, int w, int d, unsigned yfg, unsigned ypl, int c0,
+                                         RawRow<MODE>& r) {
+    // yfg / ypl: lane byte offsets blane(y, w + 2) * 4 (image planes) and blane(y, w) * 4 (a, b)
+    if (MODE == GUID) {
+#pragma unroll
+        for (int t = 0; t < SUBW; ++t) {
+            int c = c0 + t;
+            c = c < 0 ? 0 : (c >= w ? w - 1 : c);
+            r.u[0][t] = bld(P.fg1, yfg, (unsigned)(c + 1) * 256u);
+        }
+    } else if (MODE == S1) {
+#pragma unroll
+        for (int t = 0; t < SUBW; ++t) {
+            int c = c0 + t;
+            c = c < 0 ? 0 : (c >= w ? w - 1 : c);
+            int xx = c + d;
+            xx = xx < -1 ? -1 : (xx > w ? w : xx);  // sentinel columns at -1 and w
+            r.u[0][t] = bld(P.fg1, yfg, (unsigned)(c + 1) * 256u);
+            r.u[1][t] = bld(P.fg2, yfg, (unsigned)(xx + 1) * 256u);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < SUBW; ++t) {
+            int c = c0 + t;
+            c = c < 0 ? 0 : (c >= w ? w - 1 : c);
+            r.u[0][t] = bld(P.srcA, ypl, (unsigned)c * 256u);
+            r.u[1][t] = bld(P.srcB, ypl, (unsigned)c * 256u);
+        }
+    }
+}
+
+// the two scanned quantities of column t from the raw operands (same arithmetic as Source::load)
+template <int MODE>
+__device__ __forceinline__ void raw_eval(const RawRow<MODE>& r, int t, const CostConst& cc, float& v0,
+                                         float& v1) {
+    if (MODE == GUID) {
+        v0 = (float)__builtin_bit_cast(fg_t, r.u[0][t]).x;
+        v1 = v0 * v0;
+    } else if (MODE == S1) {
+        cost_pair(__builtin_bit_cast(fg_t, r.u[0][t]), __builtin_bit_cast(fg_t, r.u[1][t]), cc, v0, v1);
+    } else {
+        v0 = __builtin_bit_cast(float, r.u[0][t]);
+        v1 = __builtin_bit_cast(float, r.u[1][t]);
     }
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) void k_v2_walk(Launch L) {
+__global__ __launch_bounds__(256, 2) void k_v2_walk(Launch L) {
     // flat allocation with a small tail pad: the batched phase-B reads of masked-off columns may
     // run up to PB*NSUB + 2R + 1 floats past the last ring row
     __shared__ float ring_s[2 * RR * PITCH + 32];
     float (*ring)[RR][PITCH] = reinterpret_cast<float (*)[RR][PITCH]>(ring_s);
     const Args& a = L.v[blockIdx.z];
     const int k = blockIdx.x, slice = blockIdx.y;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // readfirstlane: the wave index is uniform but the compiler cannot know -- without it every
+    // per-column pointer and bounds test below is computed per lane in VGPRs
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int R = a.R, w = a.w, h = a.h, hp = a.hp, ow = a.ow;
     const int xs = k * ow, cs = xs - (R + 1);
     const int dj = 2 * R + 1;
     const size_t plane = (size_t)w * hp;
     const int nbands = (h + BH - 1) / BH;
+    const CostConst cc = a.cc;
     // strips whose every output column has an unclipped window in x take the fast phase B
     const bool x_interior = (cs >= 0) && (xs + ow - 1 + R <= w - 1);
     // phase C ownership: thread -> (integral, column of the tile)
     const int ci = tid / TW, cj = tid - ci * TW;
     float S = -0.0f;
-    const float* __restrict__ meanT = a.meanT;
-    const float* __restrict__ cinvT = a.cinvT;
-    const float* __restrict__ srcF1 = a.F1;
-    float* __restrict__ dstA = (MODE == GUID) ? a.dstA : a.dstA + (size_t)slice * plane;
-    float* __restrict__ dstB = (MODE == GUID) ? a.dstB : (MODE == S1 ? a.dstB + (size_t)slice * plane : nullptr);
+    const size_t pbytes = plane * sizeof(float);
+    const size_t fgbytes = (size_t)(w + 2) * hp * sizeof(fg_t);
+    Planes P;
+    P.fg1 = mk_rsrc(a.FG1, fgbytes);
+    P.fg2 = mk_rsrc(MODE == S1 ? a.FG2 : a.FG1, fgbytes);
+    P.mean = mk_rsrc(MODE == S1 ? a.meanT : a.dstA, pbytes);
+    P.cinv = mk_rsrc(MODE == S1 ? a.cinvT : a.dstA, pbytes);
+    P.srcA = mk_rsrc(MODE == S2 ? a.srcA + (size_t)slice * plane : a.dstA, pbytes);
+    P.srcB = mk_rsrc(MODE == S2 ? a.srcB + (size_t)slice * plane : a.dstA, pbytes);
+    P.dstA = mk_rsrc(MODE == GUID ? a.dstA : a.dstA + (size_t)slice * plane, pbytes);
+    P.dstB = mk_rsrc(MODE == GUID ? a.dstB : (MODE == S1 ? a.dstB + (size_t)slice * plane : a.dstA), pbytes);
+    // this wave's row-carry columns (sub-strip `wave` of strip k)
+    P.car0 = mk_rsrc(a.carry + ((size_t)(slice * 2 + 0) * a.nsegs + 4 * k + wave) * hp, (size_t)hp * 4);
+    P.car1 = mk_rsrc(a.carry + ((size_t)(slice * 2 + 1) * a.nsegs + 4 * k + wave) * hp, (size_t)hp * 4);
+    const int dsl = a.d0 + slice;
+    const int j0 = wave * SUBW;
+    const int cbeg = cs + j0;
+
+    // operands of phase R are loaded one band ahead (their latency hides behind phase B)
+    RawRow<MODE> raw;
+    float cin0, cin1;
+    {
+        const int y = min(lane, h - 1);
+        cin0 = bldf(P.car0, (unsigned)y * 4u, 0);
+        cin1 = bldf(P.car1, (unsigned)y * 4u, 0);
+        raw_load<MODE>(P, w, dsl, blane(y, w + 2) * 4u, blane(y, w) * 4u, cbeg, raw);
+    }
 
     for (int b = 0; b < nbands; ++b) {
         const int y0 = b * BH;
         const int rows = min(BH, h - y0);
         // ---------------- phase R: LANE = ROW, wave -> sub-strip --------------------------------
         if (lane < rows) {
-            const int y = y0 + lane;
-            const int g = 4 * k + wave;
-            float acc0 = a.carry[((size_t)(slice * 2 + 0) * a.nsegs + g) * hp + y];
-            float acc1 = a.carry[((size_t)(slice * 2 + 1) * a.nsegs + g) * hp + y];
-            Source<MODE> src(a, slice, y);
-            const int rr = ring_row(y);
-            const int j0 = wave * SUBW;
+            const int rr = ring_row(y0 + lane);
             float* r0 = &ring[0][rr][j0];
             float* r1 = &ring[1][rr][j0];
-            const int cbeg = cs + j0;
+            float acc0 = cin0, acc1 = cin1;
 #pragma unroll
-            for (int jb = 0; jb < SUBW; jb += RBATCH) {
-                float v0[RBATCH], v1[RBATCH];
-                src.template load<RBATCH>(cbeg + jb, v0, v1);
+            for (int t = 0; t < SUBW; ++t) {
+                const int c = cbeg + t;
+                if (c >= 0 && c < w) {
+                    float v0, v1;
+                    raw_eval<MODE>(raw, t, cc, v0, v1);
+                    acc0 = v0 + acc0;
+                    acc1 = v1 + acc1;
+                    r0[t] = acc0;
+                    r1[t] = acc1;
+                }
+            }
+        }
+        // phase B geometry of this lane (first 64 output rows of the band)
+        const int ylo = (b == 0) ? 0 : y0 - R;
+        const int yhi = (b == nbands - 1) ? h : y0 + BH - R;
+        // global operands of phase B for all of this wave's columns: in flight during phase C
+        float gA[NCB], gB[NCB];
+        if (x_interior && MODE != GUID) {
+            const int yoc = min(ylo + lane, yhi - 1);
+            const unsigned yob = blane(yoc, w) * 4u, yof = blane(yoc, w + 2) * 4u;
 #pragma unroll
-                for (int t = 0; t < RBATCH; ++t) {
-                    const int c = cbeg + jb + t;
-                    if (c >= 0 && c < w) {
-                        acc0 = v0[t] + acc0;
-                        acc1 = v1[t] + acc1;
-                        r0[jb + t] = acc0;
-                        r1[jb + t] = acc1;
-                    }
+            for (int i = 0; i < NCB; ++i) {
+                const int m = wave + i * NSUB;
+                const unsigned cob = (unsigned)(xs + (m < ow ? m : 0)) * 256u;   // uniform
+                if (MODE == S1) { gA[i] = bldf(P.mean, yob, cob); gB[i] = bldf(P.cinv, yob, cob); }
+                if (MODE == S2) {
+                    gA[i] = (float)__builtin_bit_cast(fg_t, bld(P.fg1, yof, cob + 256u)).x;
+                    gB[i] = 0.0f;
                 }
             }
         }
@@ -346,11 +499,16 @@ __global__ __launch_bounds__(256) void k_v2_walk(Launch L) {
                 rr = (rr + 1 == RR) ? 0 : rr + 1;
             }
         }
+        // next band's phase-R operands: in flight during phase B
+        if (b + 1 < nbands) {
+            const int y = min(y0 + BH + lane, h - 1);
+            cin0 = bldf(P.car0, (unsigned)y * 4u, 0);
+            cin1 = bldf(P.car1, (unsigned)y * 4u, 0);
+            raw_load<MODE>(P, w, dsl, blane(y, w + 2) * 4u, blane(y, w) * 4u, cbeg, raw);
+        }
         __syncthreads();
         // ---------------- phase B: LANE = ROW, box means + stage arithmetic --------------------
-        const int ylo = (b == 0) ? 0 : y0 - R;
-        const int yhi = (b == nbands - 1) ? h : y0 + BH - R;
-        for (int yo = ylo + lane; yo < yhi; yo += 64) {
+        for (int yo = ylo + lane, pass = 0; yo < yhi; yo += 64, ++pass) {
             const int ymax = min(h - 1, yo + R);
             const int ymin = yo - R - 1;
             const bool hy = ymin >= 0;
@@ -361,51 +519,59 @@ __global__ __launch_bounds__(256) void k_v2_walk(Launch L) {
                 // window width is 2R+1 for every column of the strip: per-lane area and reciprocal
                 const float area = (float)(dj * ych);
                 const float rarea = 1.0f / area;
-                const float* b1 = &ring[0][rr1][0];
-                const float* b0 = &ring[0][rr0][0];
-                for (int mb = wave; mb < ow; mb += NSUB * PB) {
-                    const size_t Tb = (size_t)(xs + mb) * hp + yo;
-                    float ga[PB], gb[PB];
+                const float* b1 = &ring[0][rr1][wave];
+                const float* b0 = &ring[0][rr0][wave];
+                const unsigned cob0 = (unsigned)(xs + wave) * 256u;   // uniform
+                const unsigned uyo = (unsigned)yo;
+                const unsigned ypl = blane(yo, w) * 4u, yfg = blane(yo, w + 2) * 4u;
 #pragma unroll
-                    for (int t = 0; t < PB; ++t) {
-                        const bool ok = mb + t * NSUB < ow;
-                        const size_t T = ok ? Tb + (size_t)(t * NSUB) * hp : Tb;
-                        ga[t] = 0.0f; gb[t] = 0.0f;
-                        if (MODE == S1) { ga[t] = meanT[T]; gb[t] = cinvT[T]; }
-                        if (MODE == S2) { ga[t] = srcF1[T + hp]; }
-                    }
-                    const float* p1 = b1 + mb;
-                    const float* p0 = b0 + mb;
-                    float s11[PB], s10[PB], s01[PB], s00[PB], u11[PB], u10[PB], u01[PB], u00[PB];
+                for (int ib = 0; ib < NBATCH; ++ib) {
+                    const int mb = wave + ib * PB * NSUB;
+                    if (mb < ow) {
+                        const float* p1 = b1 + ib * PB * NSUB;
+                        const float* p0 = b0 + ib * PB * NSUB;
+                        float s11[PB], s10[PB], s01[PB], s00[PB], u11[PB], u10[PB], u01[PB], u00[PB];
 #pragma unroll
-                    for (int t = 0; t < PB; ++t) {
-                        s10[t] = p1[t * NSUB];            s11[t] = p1[t * NSUB + dj];
-                        s00[t] = p0[t * NSUB];            s01[t] = p0[t * NSUB + dj];
-                        u10[t] = p1[t * NSUB + RR * PITCH];  u11[t] = p1[t * NSUB + dj + RR * PITCH];
-                        u00[t] = p0[t * NSUB + RR * PITCH];  u01[t] = p0[t * NSUB + dj + RR * PITCH];
-                    }
+                        for (int t = 0; t < PB; ++t) {
+                            s10[t] = p1[t * NSUB];                s11[t] = p1[t * NSUB + dj];
+                            s00[t] = p0[t * NSUB];                s01[t] = p0[t * NSUB + dj];
+                            u10[t] = p1[t * NSUB + RR * PITCH];   u11[t] = p1[t * NSUB + dj + RR * PITCH];
+                            u00[t] = p0[t * NSUB + RR * PITCH];   u01[t] = p0[t * NSUB + dj + RR * PITCH];
+                        }
 #pragma unroll
-                    for (int t = 0; t < PB; ++t) {
-                        if (mb + t * NSUB < ow) {
-                            float val0 = s11[t] - s10[t];
-                            float val1 = u11[t] - u10[t];
-                            float t0 = val0 - s01[t], t1 = val1 - u01[t];
-                            val0 = hy ? t0 : val0;  val1 = hy ? t1 : val1;
-                            t0 = val0 + s00[t];     t1 = val1 + u00[t];
-                            val0 = hy ? t0 : val0;  val1 = hy ? t1 : val1;
-                            float m0 = div_small_int(val0, area, rarea);
-                            float m1 = div_small_int(val1, area, rarea);
-                            const bool tiny = (fabsf(val0) < 0x1p-100f) || (fabsf(val1) < 0x1p-100f);
-                            if (__any(tiny)) {
-                                m0 = 1.0f * val0 / area;
-                                m1 = 1.0f * val1 / area;
+                        for (int t = 0; t < PB; ++t) {
+                            const int i = ib * PB + t;
+                            if (i < NCB && mb + t * NSUB < ow) {
+                                float val0 = s11[t] - s10[t];
+                                float val1 = u11[t] - u10[t];
+                                float t0 = val0 - s01[t], t1 = val1 - u01[t];
+                                val0 = hy ? t0 : val0;  val1 = hy ? t1 : val1;
+                                t0 = val0 + s00[t];     t1 = val1 + u00[t];
+                                val0 = hy ? t0 : val0;  val1 = hy ? t1 : val1;
+                                float m0 = div_small_int(val0, area, rarea);
+                                float m1 = div_small_int(val1, area, rarea);
+                                const bool tiny = (fabsf(val0) < 0x1p-100f) || (fabsf(val1) < 0x1p-100f);
+                                if (__any(tiny)) {
+                                    m0 = 1.0f * val0 / area;
+                                    m1 = 1.0f * val1 / area;
+                                }
+                                const unsigned cob = cob0 + (unsigned)(i * NSUB) * 256u;   // uniform
+                                float ga = 0.0f, gb = 0.0f;
+                                if (MODE != GUID) {
+                                    if (pass == 0) { ga = gA[i < NCB ? i : 0]; gb = gB[i < NCB ? i : 0]; }
+                                    else if (MODE == S1) { ga = bldf(P.mean, ypl, cob); gb = bldf(P.cinv, ypl, cob); }
+                                    else { ga = (float)__builtin_bit_cast(fg_t, bld(P.fg1, yfg, cob + 256u)).x; }
+                                }
+                                stage_out<MODE>(a, P, m0, m1, ga, gb, xs + mb + t * NSUB, uyo, ypl, cob);
                             }
-                            stage_out<MODE>(a, m0, m1, ga[t], gb[t], dstA, dstB,
-                                            Tb + (size_t)(t * NSUB) * hp, xs + mb + t * NSUB, yo);
                         }
                     }
+                    // keep the batches apart: without this the scheduler hoists every batch's LDS
+                    // reads to the top of the unrolled loop and spills
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
+                const unsigned ypl = blane(yo, w) * 4u, yfg = blane(yo, w + 2) * 4u;
                 for (int mb = wave; mb < ow; mb += NSUB * PB) {
                     float ga[PB], gb[PB];
 #pragma unroll
@@ -413,10 +579,10 @@ __global__ __launch_bounds__(256) void k_v2_walk(Launch L) {
                         const int m = mb + t * NSUB;
                         int xo = xs + m;
                         xo = (m < ow && xo < w) ? xo : (w - 1);
-                        const size_t T = (size_t)xo * hp + yo;
+                        const unsigned cob = (unsigned)xo * 256u;   // uniform
                         ga[t] = 0.0f; gb[t] = 0.0f;
-                        if (MODE == S1) { ga[t] = meanT[T]; gb[t] = cinvT[T]; }
-                        if (MODE == S2) { ga[t] = srcF1[T + hp]; }
+                        if (MODE == S1) { ga[t] = bldf(P.mean, ypl, cob); gb[t] = bldf(P.cinv, ypl, cob); }
+                        if (MODE == S2) { ga[t] = (float)__builtin_bit_cast(fg_t, bld(P.fg1, yfg, cob + 256u)).x; }
                     }
 #pragma unroll
                     for (int t = 0; t < PB; ++t) {
@@ -436,8 +602,8 @@ __global__ __launch_bounds__(256) void k_v2_walk(Launch L) {
                             if (hx && hy) { val0 += ring[0][rr0][jmin]; val1 += ring[1][rr0][jmin]; }
                             const float m0 = 1.0f * val0 / area;
                             const float m1 = 1.0f * val1 / area;
-                            stage_out<MODE>(a, m0, m1, ga[t], gb[t], dstA, dstB,
-                                            (size_t)xo * hp + yo, xo, yo);
+                            stage_out<MODE>(a, P, m0, m1, ga[t], gb[t], xo, (unsigned)yo, ypl,
+                                            (unsigned)xo * 256u);
                         }
                     }
                 }
@@ -462,7 +628,7 @@ __global__ __launch_bounds__(64) void k_v2_wta(WtaArgs wa, int w, int h, int hp,
     const int x = blockIdx.y;
     if (y >= h) return;
     const size_t plane = (size_t)w * hp;
-    const float* __restrict__ q = wa.qT[blockIdx.z] + (size_t)x * hp + y;
+    const float* __restrict__ q = wa.qT[blockIdx.z] + blane(y, w) + bcol(x);
     uint64_t* keys = wa.keys[blockIdx.z];
     const size_t id = (size_t)y * w + x;
     uint64_t key = keys[id];
@@ -494,7 +660,7 @@ __global__ void k_v2_untranspose(const float* __restrict__ qT, float* __restrict
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
     for (int i = ty; i < 32; i += 8) {
         int x = x0 + i, y = y0 + tx;
-        if (x < w && y < h) t[i][tx] = qT[(size_t)z * planeT + (size_t)x * hp + y];
+        if (x < w && y < h) t[i][tx] = qT[(size_t)z * planeT + blane(y, w) + bcol(x)];
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
@@ -535,7 +701,7 @@ bool v2_supported(const smx_params* p) { return p->radius >= 0 && p->radius <= v
 size_t v2_workspace_bytes(int w, int h, int R, int nslices) {
     (void)R;  // the largest radius has the narrowest strips, i.e. the most carry segments
     V2Layout L9 = v2_layout(w, h, v2::RMAX);
-    size_t fl = 4 * L9.padded_plane + 2 * L9.plane + L9.carry_slice +
+    size_t fl = 2 * L9.padded_plane + 2 * L9.plane + L9.carry_slice +
                 (size_t)nslices * (3 * L9.plane + L9.carry_slice);
     return fl * sizeof(float) + 24 * 256;
 }
@@ -593,8 +759,9 @@ int aggregate_v2(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     const size_t per_slice = (3 * L.plane + L.carry_slice) * sizeof(float);
     // fixed planes: the two images' F/G are shared by both views of a pair
     const int nimg = 2;
-    float *F[2], *G[2], *meanT[2], *cinvT[2], *gcarry[2];
-    for (int i = 0; i < nimg; ++i) { F[i] = carve(L.padded_plane); G[i] = carve(L.padded_plane); }
+    v2::fg_t* FG[2];
+    float *meanT[2], *cinvT[2], *gcarry[2];
+    for (int i = 0; i < nimg; ++i) FG[i] = (v2::fg_t*)carve(L.padded_plane);
     for (int v = 0; v < nviews; ++v) {
         meanT[v] = carve(L.plane); cinvT[v] = carve(L.plane); gcarry[v] = carve(L.carry_slice);
     }
@@ -618,7 +785,7 @@ int aggregate_v2(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     // image 0 = guide of view 0; image 1 = the other image (guide of view 1 in a pair)
     v2::PrepArgs pa;
     pa.I[0] = d_guide[0]; pa.I[1] = nviews == 2 ? d_guide[1] : d_other[0];
-    pa.F[0] = F[0]; pa.F[1] = F[1]; pa.G[0] = G[0]; pa.G[1] = G[1];
+    pa.FG[0] = FG[0]; pa.FG[1] = FG[1];
     hipLaunchKernelGGL(v2::k_v2_prep, dim3(L.hp / 64, w + 2, 2), dim3(64), 0, st, pa, w, h, L.hp);
     SMX_HIP(hipGetLastError());
     ++nl;
@@ -628,7 +795,7 @@ int aggregate_v2(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     for (int v = 0; v < nviews; ++v) {
         v2::Args& a = base_l.v[v];
         a.w = w; a.h = h; a.hp = L.hp; a.R = R; a.ow = L.ow; a.nstrips = L.nstrips; a.nsegs = L.nsegs;
-        a.F1 = F[v]; a.G1 = G[v]; a.F2 = F[v ^ 1]; a.G2 = G[v ^ 1];
+        a.FG1 = FG[v]; a.FG2 = FG[v ^ 1];
         a.cc = make_cost_const(p);
         a.eps = p->eps;
     }
