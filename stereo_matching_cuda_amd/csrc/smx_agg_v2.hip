@@ -38,18 +38,18 @@ namespace smx {
 namespace v2 {
 
 constexpr int TW = 104;            // columns of S computed per strip
-constexpr int NSUB = 4;            // sub-strips per strip = waves per workgroup
-constexpr int SUBW = TW / NSUB;    // 26
+constexpr int NSUB = 8;            // sub-strips per strip = waves per workgroup
+constexpr int SUBW = TW / NSUB;    // 13
+constexpr int NTHREADS = NSUB * 64;
 constexpr int BH = 64;             // band height = wave width
 constexpr int RMAX = 9;            // largest supported box radius
 constexpr int RR = 96;             // ring rows >= BH + 2*RMAX + 2; multiple of 32 so that the wrap
                                    // of a band inside the ring does not shift LDS banks
 constexpr int PITCH = TW + 1;      // odd pitch: LANE=ROW accesses hit distinct banks
-constexpr int RBATCH = 13;         // columns per load batch in phase R (SUBW = 2 batches)
 constexpr int PB = 4;              // output columns per load batch in phase B
 constexpr int CB = 16;             // columns per load batch of the carry prepass
 static_assert(RR >= BH + 2 * RMAX + 2 && RR % 32 == 0, "ring too small");
-static_assert(SUBW % RBATCH == 0 && 2 * TW <= 256, "tile geometry");
+static_assert(TW % NSUB == 0 && 2 * TW <= NTHREADS, "tile geometry");
 
 enum Mode { GUID = 0, S1 = 1, S2 = 2 };
 
@@ -97,8 +97,10 @@ __device__ __forceinline__ uint32_t bld(rsrc_t r, unsigned voff, unsigned soff) 
 __device__ __forceinline__ float bldf(rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
+// streamed outputs (a, b, q): sc1 stores do not keep the line in the XCD's L2, which the small image
+// / guidance planes re-read by every slice need more (MI355X_MICROARCH.md, "stores of each flavour")
 __device__ __forceinline__ void bstf(rsrc_t r, unsigned voff, unsigned soff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, 16);
 }
 
 struct Args {
@@ -110,6 +112,8 @@ struct Args {
     float* dstA; float* dstB;           // GUID: meanT, cinvT; S1: aT, bT; S2: qT (dstB unused)
     uint8_t* mean_u8;                   // GUID optional, row-major [y*w + x]
     float* carry;                       // [(slice*2 + i)*nsegs + g][hp]
+    const int* ev_start;                // segment start columns, ascending (k_v2_events)
+    const int* ev_seg;                  // segment id g of each event
     int d0;                             // disparity of local slice 0
     CostConst cc;
     double eps;
@@ -121,7 +125,7 @@ struct Launch {
 };
 
 __device__ __forceinline__ int seg_c0(const Args& a, int g) {
-    return (g >> 2) * a.ow - (a.R + 1) + (g & 3) * SUBW;
+    return (g / NSUB) * a.ow - (a.R + 1) + (g % NSUB) * SUBW;
 }
 
 // x / d, correctly rounded, for an integer-valued d in [1, 361] with r = RN(1/d): one residual
@@ -238,6 +242,22 @@ __global__ __launch_bounds__(64) void k_v2_prep(PrepArgs pa, int w, int h, int h
 // ---------------------------------------------------------------------------------------------
 // carry prepass.  grid (nbands, nslices, nviews), block 64 (LANE = ROW).
 // ---------------------------------------------------------------------------------------------
+// Segment g = (strip k, sub-strip q) starts at column seg_c0(g).  With 8 sub-strips per strip the
+// starts are not monotone in g (the last sub-strips of strip k lie right of the first of strip k+1),
+// so the prepass walks an event list sorted by start column.  One block, built once per call.
+__global__ void k_v2_events(int nsegs, int ow, int R, int* __restrict__ ev_start, int* __restrict__ ev_seg) {
+    for (int g = threadIdx.x; g < nsegs; g += blockDim.x) {
+        const int c = (g / NSUB) * ow - (R + 1) + (g % NSUB) * SUBW;
+        int rank = 0;
+        for (int o = 0; o < nsegs; ++o) {
+            const int co = (o / NSUB) * ow - (R + 1) + (o % NSUB) * SUBW;
+            rank += (co < c) || (co == c && o < g);
+        }
+        ev_start[rank] = c;
+        ev_seg[rank] = g;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) void k_v2_carry(Launch L) {
     const Args& a = L.v[blockIdx.z];
@@ -247,15 +267,18 @@ __global__ __launch_bounds__(64) void k_v2_carry(Launch L) {
     Source<MODE> src(a, slice, y);
     float* c0p = a.carry + ((size_t)(slice * 2 + 0) * a.nsegs) * a.hp + y;
     float* c1p = a.carry + ((size_t)(slice * 2 + 1) * a.nsegs) * a.hp + y;
+    const int* __restrict__ evs = a.ev_start;
+    const int* __restrict__ evg = a.ev_seg;
     float acc0 = -0.0f, acc1 = -0.0f;
-    int g = 0;
+    int e = 0;
     // segments that start at or left of column 0 begin with the additive identity
-    while (g < a.nsegs && seg_c0(a, g) <= 0) {
+    while (e < a.nsegs && evs[e] <= 0) {
+        const int g = evg[e];
         c0p[(size_t)g * a.hp] = acc0;
         c1p[(size_t)g * a.hp] = acc1;
-        ++g;
+        ++e;
     }
-    int next = g < a.nsegs ? seg_c0(a, g) : 0x7fffffff;
+    int next = e < a.nsegs ? evs[e] : 0x7fffffff;
     for (int cb = 0; cb < a.w; cb += CB) {
         float v0[CB], v1[CB];
         src.template load<CB>(cb, v0, v1);
@@ -263,18 +286,20 @@ __global__ __launch_bounds__(64) void k_v2_carry(Launch L) {
         for (int t = 0; t < CB; ++t) {
             const int c = cb + t;
             if (c < a.w) {
-                if (c == next) {   // wave-uniform: carry of segment g = row sum left of column c
+                while (c == next) {   // wave-uniform: carry of segment g = row sum left of column c
+                    const int g = evg[e];
                     c0p[(size_t)g * a.hp] = acc0;
                     c1p[(size_t)g * a.hp] = acc1;
-                    ++g;
-                    next = g < a.nsegs ? seg_c0(a, g) : 0x7fffffff;
+                    ++e;
+                    next = e < a.nsegs ? evs[e] : 0x7fffffff;
                 }
                 acc0 = v0[t] + acc0;
                 acc1 = v1[t] + acc1;
             }
         }
     }
-    for (; g < a.nsegs; ++g) {     // segments starting at or beyond column w are never read
+    for (; e < a.nsegs; ++e) {     // segments starting at or beyond column w are never read
+        const int g = evg[e];
         c0p[(size_t)g * a.hp] = acc0;
         c1p[(size_t)g * a.hp] = acc1;
     }
@@ -382,10 +407,10 @@ __device__ __forceinline__ void raw_eval(const RawRow<MODE>& r, int t, const Cos
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void k_v2_walk(Launch L) {
+__global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
     // flat allocation with a small tail pad: the batched phase-B reads of masked-off columns may
     // run up to PB*NSUB + 2R + 1 floats past the last ring row
-    __shared__ float ring_s[2 * RR * PITCH + 32];
+    __shared__ float ring_s[2 * RR * PITCH + 64];
     float (*ring)[RR][PITCH] = reinterpret_cast<float (*)[RR][PITCH]>(ring_s);
     const Args& a = L.v[blockIdx.z];
     const int k = blockIdx.x, slice = blockIdx.y;
@@ -415,8 +440,8 @@ __global__ __launch_bounds__(256, 2) void k_v2_walk(Launch L) {
     P.dstA = mk_rsrc(MODE == GUID ? a.dstA : a.dstA + (size_t)slice * plane, pbytes);
     P.dstB = mk_rsrc(MODE == GUID ? a.dstB : (MODE == S1 ? a.dstB + (size_t)slice * plane : a.dstA), pbytes);
     // this wave's row-carry columns (sub-strip `wave` of strip k)
-    P.car0 = mk_rsrc(a.carry + ((size_t)(slice * 2 + 0) * a.nsegs + 4 * k + wave) * hp, (size_t)hp * 4);
-    P.car1 = mk_rsrc(a.carry + ((size_t)(slice * 2 + 1) * a.nsegs + 4 * k + wave) * hp, (size_t)hp * 4);
+    P.car0 = mk_rsrc(a.carry + ((size_t)(slice * 2 + 0) * a.nsegs + NSUB * k + wave) * hp, (size_t)hp * 4);
+    P.car1 = mk_rsrc(a.carry + ((size_t)(slice * 2 + 1) * a.nsegs + NSUB * k + wave) * hp, (size_t)hp * 4);
     const int dsl = a.d0 + slice;
     const int j0 = wave * SUBW;
     const int cbeg = cs + j0;
@@ -688,7 +713,7 @@ static V2Layout v2_layout(int w, int h, int R) {
     L.hp = (h + 63) / 64 * 64;
     L.ow = v2::TW - (2 * R + 1);
     L.nstrips = (w + L.ow - 1) / L.ow;
-    L.nsegs = 4 * L.nstrips;
+    L.nsegs = v2::NSUB * L.nstrips;
     L.padded_plane = (size_t)(w + 2) * L.hp;
     L.plane = (size_t)w * L.hp;
     L.carry_slice = (size_t)2 * L.nsegs * L.hp;
@@ -701,7 +726,7 @@ bool v2_supported(const smx_params* p) { return p->radius >= 0 && p->radius <= v
 size_t v2_workspace_bytes(int w, int h, int R, int nslices) {
     (void)R;  // the largest radius has the narrowest strips, i.e. the most carry segments
     V2Layout L9 = v2_layout(w, h, v2::RMAX);
-    size_t fl = 2 * L9.padded_plane + 2 * L9.plane + L9.carry_slice +
+    size_t fl = 2 * L9.padded_plane + 2 * L9.plane + L9.carry_slice + 2 * (size_t)L9.nsegs +
                 (size_t)nslices * (3 * L9.plane + L9.carry_slice);
     return fl * sizeof(float) + 24 * 256;
 }
@@ -731,7 +756,7 @@ static int launch_carry(const v2::Launch& L, int nslices, int nviews, hipStream_
 template <int MODE>
 static int launch_walk(const v2::Launch& L, int nslices, int nviews, hipStream_t st) {
     const v2::Args& a = L.v[0];
-    hipLaunchKernelGGL(v2::k_v2_walk<MODE>, dim3(a.nstrips, nslices, nviews), dim3(256), 0, st, L);
+    hipLaunchKernelGGL(v2::k_v2_walk<MODE>, dim3(a.nstrips, nslices, nviews), dim3(v2::NTHREADS), 0, st, L);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
@@ -765,6 +790,8 @@ int aggregate_v2(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     for (int v = 0; v < nviews; ++v) {
         meanT[v] = carve(L.plane); cinvT[v] = carve(L.plane); gcarry[v] = carve(L.carry_slice);
     }
+    int* ev_start = (int*)carve((size_t)L.nsegs);
+    int* ev_seg = (int*)carve((size_t)L.nsegs);
     const int total = s_end - s_begin;
     size_t fit = avail > 8 * 256 ? (avail - 8 * 256) / (per_slice * nviews) : 0;
     if (oom || fit < 1)
@@ -788,7 +815,9 @@ int aggregate_v2(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     pa.FG[0] = FG[0]; pa.FG[1] = FG[1];
     hipLaunchKernelGGL(v2::k_v2_prep, dim3(L.hp / 64, w + 2, 2), dim3(64), 0, st, pa, w, h, L.hp);
     SMX_HIP(hipGetLastError());
-    ++nl;
+    hipLaunchKernelGGL(v2::k_v2_events, dim3(1), dim3(256), 0, st, L.nsegs, L.ow, R, ev_start, ev_seg);
+    SMX_HIP(hipGetLastError());
+    nl += 2;
 
     v2::Launch base_l;
     memset(&base_l, 0, sizeof(base_l));
@@ -798,6 +827,7 @@ int aggregate_v2(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         a.FG1 = FG[v]; a.FG2 = FG[v ^ 1];
         a.cc = make_cost_const(p);
         a.eps = p->eps;
+        a.ev_start = ev_start; a.ev_seg = ev_seg;
     }
     // ---- guidance statistics on the side stream, overlapped with the first stage-1 carry prepass
     if ((rc = ensure_side_stream())) return rc;
