@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_PKG, "_build", "libsmx_hip.so")
+# SMX_LIB_PATH: load another build of the same C-ABI (timing-experiment builds, tools/exp_build.sh)
+SO_PATH = os.environ.get("SMX_LIB_PATH") or os.path.join(_PKG, "_build", "libsmx_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "smx.h")
 
 

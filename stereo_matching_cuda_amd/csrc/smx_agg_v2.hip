@@ -31,6 +31,10 @@
 // Must be compiled with -ffp-contract=off.
 #include <string.h>
 
+#ifndef SMX_EXP
+#define SMX_EXP 0   // timing experiments (tools/exp_build.sh); 0 = product build
+#endif
+
 #include "smx_common.h"
 #include "smx_launch.h"
 
@@ -92,7 +96,11 @@ __device__ __forceinline__ rsrc_t mk_rsrc(const void* p, size_t bytes) {
                                              0x00020000);
 }
 __device__ __forceinline__ uint32_t bld(rsrc_t r, unsigned voff, unsigned soff) {
+#if SMX_EXP == 3   // timing experiment: no global loads in the walker
+    return voff + soff;
+#else
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
+#endif
 }
 __device__ __forceinline__ float bldf(rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
@@ -100,7 +108,11 @@ __device__ __forceinline__ float bldf(rsrc_t r, unsigned voff, unsigned soff) {
 // streamed outputs (a, b, q): sc1 stores do not keep the line in the XCD's L2, which the small image
 // / guidance planes re-read by every slice need more (MI355X_MICROARCH.md, "stores of each flavour")
 __device__ __forceinline__ void bstf(rsrc_t r, unsigned voff, unsigned soff, float v) {
+#if SMX_EXP == 1   // timing experiment: no output stores (keep the value alive)
+    asm volatile("" ::"v"(v));
+#else
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, 16);
+#endif
 }
 
 struct Args {
@@ -533,6 +545,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
         }
         __syncthreads();
         // ---------------- phase B: LANE = ROW, box means + stage arithmetic --------------------
+#if SMX_EXP == 2   // timing experiment: no phase B
+        if (gA[0] == 12345.0f)
+#endif
         for (int yo = ylo + lane, pass = 0; yo < yhi; yo += 64, ++pass) {
             const int ymax = min(h - 1, yo + R);
             const int ymin = yo - R - 1;
