@@ -134,6 +134,7 @@ struct Args {
 // Both views of a pair travel in one launch: blockIdx.z selects the view.
 struct Launch {
     Args v[2];
+    int nslices, nviews;
 };
 
 __device__ __forceinline__ int seg_c0(const Args& a, int g) {
@@ -181,39 +182,41 @@ struct Source {
         sa = MODE == S2 ? a.srcA + (size_t)slice * plane + blane(y, a.w) : nullptr;
         sb = MODE == S2 ? a.srcB + (size_t)slice * plane + blane(y, a.w) : nullptr;
     }
+    // raw operands of NB columns (issue only; nothing waits here)
     template <int NB>
-    __device__ __forceinline__ void load(int c0, float (&v0)[NB], float (&v1)[NB]) const {
-        if (MODE == GUID) {
+    struct Raw {
+        uint32_t a[NB], b[NB];
+    };
+    template <int NB>
+    __device__ __forceinline__ void fetch(int c0, Raw<NB>& r) const {
 #pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                int c = c0 + t;
-                c = c < 0 ? 0 : (c >= w ? w - 1 : c);
-                v0[t] = (float)fg1[bcol(c + 1)].x;      // chToFlOnGPU
-            }
-#pragma unroll
-            for (int t = 0; t < NB; ++t) v1[t] = v0[t] * v0[t];   // pixelMultOnGPU(d_im, d_im)
-        } else if (MODE == S1) {
-            fg_t p1[NB], p2[NB];
-#pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                int c = c0 + t;
-                c = c < 0 ? 0 : (c >= w ? w - 1 : c);
+        for (int t = 0; t < NB; ++t) {
+            int c = c0 + t;
+            c = c < 0 ? 0 : (c >= w ? w - 1 : c);
+            if (MODE == GUID) {
+                r.a[t] = __builtin_bit_cast(uint32_t, fg1[bcol(c + 1)]);
+                r.b[t] = 0;
+            } else if (MODE == S1) {
                 int xx = c + d;
                 xx = xx < -1 ? -1 : (xx > w ? w : xx);  // sentinel columns at -1 and w
-                p1[t] = fg1[bcol(c + 1)];
-                p2[t] = fg2[bcol(xx + 1)];
+                r.a[t] = __builtin_bit_cast(uint32_t, fg1[bcol(c + 1)]);
+                r.b[t] = __builtin_bit_cast(uint32_t, fg2[bcol(xx + 1)]);
+            } else {
+                r.a[t] = __builtin_bit_cast(uint32_t, sa[bcol(c)]);
+                r.b[t] = __builtin_bit_cast(uint32_t, sb[bcol(c)]);
             }
-#pragma unroll
-            for (int t = 0; t < NB; ++t) cost_pair(p1[t], p2[t], cc, v0[t], v1[t]);
+        }
+    }
+    template <int NB>
+    __device__ __forceinline__ void eval(const Raw<NB>& r, int t, float& v0, float& v1) const {
+        if (MODE == GUID) {
+            v0 = (float)__builtin_bit_cast(fg_t, r.a[t]).x;      // chToFlOnGPU
+            v1 = v0 * v0;                                        // pixelMultOnGPU(d_im, d_im)
+        } else if (MODE == S1) {
+            cost_pair(__builtin_bit_cast(fg_t, r.a[t]), __builtin_bit_cast(fg_t, r.b[t]), cc, v0, v1);
         } else {
-#pragma unroll
-            for (int t = 0; t < NB; ++t) {
-                int c = c0 + t;
-                c = c < 0 ? 0 : (c >= w ? w - 1 : c);
-                const size_t o = bcol(c);
-                v0[t] = sa[o];
-                v1[t] = sb[o];
-            }
+            v0 = __builtin_bit_cast(float, r.a[t]);
+            v1 = __builtin_bit_cast(float, r.b[t]);
         }
     }
 };
@@ -291,9 +294,11 @@ __global__ __launch_bounds__(64) void k_v2_carry(Launch L) {
         ++e;
     }
     int next = e < a.nsegs ? evs[e] : 0x7fffffff;
+    // one batch of CB columns at a time: all loads of the batch issue before the first use.
+    // (Double-buffering the batches was measured slower: +20 % on k_v2_carry<S1>.)
     for (int cb = 0; cb < a.w; cb += CB) {
-        float v0[CB], v1[CB];
-        src.template load<CB>(cb, v0, v1);
+        typename Source<MODE>::template Raw<CB> cur;
+        src.template fetch<CB>(cb, cur);
 #pragma unroll
         for (int t = 0; t < CB; ++t) {
             const int c = cb + t;
@@ -305,8 +310,10 @@ __global__ __launch_bounds__(64) void k_v2_carry(Launch L) {
                     ++e;
                     next = e < a.nsegs ? evs[e] : 0x7fffffff;
                 }
-                acc0 = v0[t] + acc0;
-                acc1 = v1[t] + acc1;
+                float v0, v1;
+                src.template eval<CB>(cur, t, v0, v1);
+                acc0 = v0 + acc0;
+                acc1 = v1 + acc1;
             }
         }
     }
@@ -323,12 +330,15 @@ __global__ __launch_bounds__(64) void k_v2_carry(Launch L) {
 __device__ __forceinline__ int ring_row(int y) { return y % RR; }
 
 // descriptors of the planes a walker workgroup touches (all wave-uniform)
+// (few descriptors on purpose: each costs 4 SGPRs for the whole kernel; planes that are neighbours
+// in the workspace share one and are told apart by a scalar byte offset)
 struct Planes {
-    rsrc_t fg1, fg2;        // padded image planes
-    rsrc_t mean, cinv;      // guidance statistics (S1 reads)
+    rsrc_t img;             // both padded image planes; fg1o / fg2o select this view's / the other
+    rsrc_t stat;            // guidance statistics mean_I, then 1/(var+eps) at +cinvo   (S1 reads)
     rsrc_t srcA, srcB;      // S2 sources (this slice's plane)
     rsrc_t dstA, dstB;      // outputs (this slice's plane)
-    rsrc_t car0, car1;      // this wave's carry columns
+    rsrc_t car;             // this wave's carry column of integral 0; integral 1 at +car1o
+    unsigned fg1o, fg2o, cinvo, car1o;
 };
 
 // per-pixel arithmetic of the stage on the two box means m0, m1; the outputs go to column xo
@@ -380,7 +390,7 @@ __device__ __forceinline__ void raw_load(const Planes& P, int w, int d, unsigned
         for (int t = 0; t < SUBW; ++t) {
             int c = c0 + t;
             c = c < 0 ? 0 : (c >= w ? w - 1 : c);
-            r.u[0][t] = bld(P.fg1, yfg, (unsigned)(c + 1) * 256u);
+            r.u[0][t] = bld(P.img, yfg, P.fg1o + (unsigned)(c + 1) * 256u);
         }
     } else if (MODE == S1) {
 #pragma unroll
@@ -389,8 +399,8 @@ __device__ __forceinline__ void raw_load(const Planes& P, int w, int d, unsigned
             c = c < 0 ? 0 : (c >= w ? w - 1 : c);
             int xx = c + d;
             xx = xx < -1 ? -1 : (xx > w ? w : xx);  // sentinel columns at -1 and w
-            r.u[0][t] = bld(P.fg1, yfg, (unsigned)(c + 1) * 256u);
-            r.u[1][t] = bld(P.fg2, yfg, (unsigned)(xx + 1) * 256u);
+            r.u[0][t] = bld(P.img, yfg, P.fg1o + (unsigned)(c + 1) * 256u);
+            r.u[1][t] = bld(P.img, yfg, P.fg2o + (unsigned)(xx + 1) * 256u);
         }
     } else {
 #pragma unroll
@@ -424,53 +434,78 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
     // run up to PB*NSUB + 2R + 1 floats past the last ring row
     __shared__ float ring_s[2 * RR * PITCH + 64];
     float (*ring)[RR][PITCH] = reinterpret_cast<float (*)[RR][PITCH]>(ring_s);
-    const Args& a = L.v[blockIdx.z];
-    const int k = blockIdx.x, slice = blockIdx.y;
+    // XCD-aware work order (speed only, never correctness): workgroups are dealt round-robin over
+    // the 8 XCDs, so give each XCD a contiguous range of the strip-major item order.  The workgroups
+    // resident on one XCD then sit in one or two strips and re-read the same image / guidance columns
+    // from that XCD's L2 instead of thrashing it with all strips (bijective remap of the guide, T1).
+    const int nslices = L.nslices, nviews = L.nviews;
+    const int T = (int)gridDim.x;
+    const int q8 = T >> 3, r8 = T & 7;
+    const int xcd = (int)blockIdx.x & 7, jx = (int)blockIdx.x >> 3;
+    const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + jx;
+    const int per_strip = nslices * nviews;
+    const int k = item / per_strip;
+    const int rem = item - k * per_strip;
+    const int slice = rem / nviews;
+    const Args& a = L.v[rem - slice * nviews];
     // readfirstlane: the wave index is uniform but the compiler cannot know -- without it every
     // per-column pointer and bounds test below is computed per lane in VGPRs
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int R = a.R, w = a.w, h = a.h, hp = a.hp, ow = a.ow;
-    const int xs = k * ow, cs = xs - (R + 1);
+    const int xs_ = k * ow, cs_ = xs_ - (R + 1);
     const int dj = 2 * R + 1;
     const size_t plane = (size_t)w * hp;
     const int nbands = (h + BH - 1) / BH;
     const CostConst cc = a.cc;
     // strips whose every output column has an unclipped window in x take the fast phase B
-    const bool x_interior = (cs >= 0) && (xs + ow - 1 + R <= w - 1);
+    const bool x_interior = (cs_ >= 0) && (xs_ + ow - 1 + R <= w - 1);
     // phase C ownership: thread -> (integral, column of the tile)
     const int ci = tid / TW, cj = tid - ci * TW;
     float S = -0.0f;
     const size_t pbytes = plane * sizeof(float);
     const size_t fgbytes = (size_t)(w + 2) * hp * sizeof(fg_t);
     Planes P;
-    P.fg1 = mk_rsrc(a.FG1, fgbytes);
-    P.fg2 = mk_rsrc(MODE == S1 ? a.FG2 : a.FG1, fgbytes);
-    P.mean = mk_rsrc(MODE == S1 ? a.meanT : a.dstA, pbytes);
-    P.cinv = mk_rsrc(MODE == S1 ? a.cinvT : a.dstA, pbytes);
+    {
+        const fg_t* lo = a.FG1 < a.FG2 ? a.FG1 : a.FG2;
+        const fg_t* hi = a.FG1 < a.FG2 ? a.FG2 : a.FG1;
+        P.img = mk_rsrc(lo, (size_t)((const char*)hi - (const char*)lo) + fgbytes);
+        P.fg1o = (unsigned)((const char*)a.FG1 - (const char*)lo);
+        P.fg2o = (unsigned)((const char*)a.FG2 - (const char*)lo);
+    }
+    P.stat = mk_rsrc(MODE == S1 ? a.meanT : a.dstA,
+                     MODE == S1 ? (size_t)((const char*)a.cinvT - (const char*)a.meanT) + pbytes : pbytes);
+    P.cinvo = MODE == S1 ? (unsigned)((const char*)a.cinvT - (const char*)a.meanT) : 0u;
     P.srcA = mk_rsrc(MODE == S2 ? a.srcA + (size_t)slice * plane : a.dstA, pbytes);
     P.srcB = mk_rsrc(MODE == S2 ? a.srcB + (size_t)slice * plane : a.dstA, pbytes);
     P.dstA = mk_rsrc(MODE == GUID ? a.dstA : a.dstA + (size_t)slice * plane, pbytes);
     P.dstB = mk_rsrc(MODE == GUID ? a.dstB : (MODE == S1 ? a.dstB + (size_t)slice * plane : a.dstA), pbytes);
-    // this wave's row-carry columns (sub-strip `wave` of strip k)
-    P.car0 = mk_rsrc(a.carry + ((size_t)(slice * 2 + 0) * a.nsegs + NSUB * k + wave) * hp, (size_t)hp * 4);
-    P.car1 = mk_rsrc(a.carry + ((size_t)(slice * 2 + 1) * a.nsegs + NSUB * k + wave) * hp, (size_t)hp * 4);
+    // this wave's row-carry columns (sub-strip `wave` of strip k): integral 0, integral 1 behind it
+    P.car1o = (unsigned)((size_t)a.nsegs * hp * sizeof(float));
+    P.car = mk_rsrc(a.carry + ((size_t)(slice * 2 + 0) * a.nsegs + NSUB * k + wave) * hp,
+                    (size_t)P.car1o + (size_t)hp * 4);
     const int dsl = a.d0 + slice;
     const int j0 = wave * SUBW;
-    const int cbeg = cs + j0;
+    const int cbeg_ = cs_ + j0;
 
     // operands of phase R are loaded one band ahead (their latency hides behind phase B)
     RawRow<MODE> raw;
     float cin0, cin1;
     {
         const int y = min(lane, h - 1);
-        cin0 = bldf(P.car0, (unsigned)y * 4u, 0);
-        cin1 = bldf(P.car1, (unsigned)y * 4u, 0);
-        raw_load<MODE>(P, w, dsl, blane(y, w + 2) * 4u, blane(y, w) * 4u, cbeg, raw);
+        cin0 = bldf(P.car, (unsigned)y * 4u, 0);
+        cin1 = bldf(P.car, (unsigned)y * 4u, P.car1o);
+        raw_load<MODE>(P, w, dsl, blane(y, w + 2) * 4u, blane(y, w) * 4u, cbeg_, raw);
     }
 
     for (int b = 0; b < nbands; ++b) {
         const int y0 = b * BH;
         const int rows = min(BH, h - y0);
+        // The unrolled phases below have ~100 wave-uniform per-column values (bounds tests, byte
+        // offsets).  They are loop invariant, so the compiler would keep them all live across the
+        // band loop and spill SGPRs to VGPR lanes (v_writelane/v_readlane in the hot loop).  Passing
+        // the column origins through an empty asm once per band makes them cheap to recompute instead.
+        int cbeg = cbeg_; int xs = xs_; int cs = cs_;
+        asm volatile("" : "+s"(cbeg), "+s"(xs), "+s"(cs));
         // ---------------- phase R: LANE = ROW, wave -> sub-strip --------------------------------
         if (lane < rows) {
             const int rr = ring_row(y0 + lane);
@@ -502,9 +537,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
             for (int i = 0; i < NCB; ++i) {
                 const int m = wave + i * NSUB;
                 const unsigned cob = (unsigned)(xs + (m < ow ? m : 0)) * 256u;   // uniform
-                if (MODE == S1) { gA[i] = bldf(P.mean, yob, cob); gB[i] = bldf(P.cinv, yob, cob); }
+                if (MODE == S1) { gA[i] = bldf(P.stat, yob, cob); gB[i] = bldf(P.stat, yob, P.cinvo + cob); }
                 if (MODE == S2) {
-                    gA[i] = (float)__builtin_bit_cast(fg_t, bld(P.fg1, yof, cob + 256u)).x;
+                    gA[i] = (float)__builtin_bit_cast(fg_t, bld(P.img, yof, P.fg1o + cob + 256u)).x;
                     gB[i] = 0.0f;
                 }
             }
@@ -539,8 +574,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
         // next band's phase-R operands: in flight during phase B
         if (b + 1 < nbands) {
             const int y = min(y0 + BH + lane, h - 1);
-            cin0 = bldf(P.car0, (unsigned)y * 4u, 0);
-            cin1 = bldf(P.car1, (unsigned)y * 4u, 0);
+            cin0 = bldf(P.car, (unsigned)y * 4u, 0);
+            cin1 = bldf(P.car, (unsigned)y * 4u, P.car1o);
             raw_load<MODE>(P, w, dsl, blane(y, w + 2) * 4u, blane(y, w) * 4u, cbeg, raw);
         }
         __syncthreads();
@@ -599,8 +634,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
                                 float ga = 0.0f, gb = 0.0f;
                                 if (MODE != GUID) {
                                     if (pass == 0) { ga = gA[i < NCB ? i : 0]; gb = gB[i < NCB ? i : 0]; }
-                                    else if (MODE == S1) { ga = bldf(P.mean, ypl, cob); gb = bldf(P.cinv, ypl, cob); }
-                                    else { ga = (float)__builtin_bit_cast(fg_t, bld(P.fg1, yfg, cob + 256u)).x; }
+                                    else if (MODE == S1) { ga = bldf(P.stat, ypl, cob); gb = bldf(P.stat, ypl, P.cinvo + cob); }
+                                    else { ga = (float)__builtin_bit_cast(fg_t, bld(P.img, yfg, P.fg1o + cob + 256u)).x; }
                                 }
                                 stage_out<MODE>(a, P, m0, m1, ga, gb, xs + mb + t * NSUB, uyo, ypl, cob);
                             }
@@ -621,8 +656,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
                         xo = (m < ow && xo < w) ? xo : (w - 1);
                         const unsigned cob = (unsigned)xo * 256u;   // uniform
                         ga[t] = 0.0f; gb[t] = 0.0f;
-                        if (MODE == S1) { ga[t] = bldf(P.mean, ypl, cob); gb[t] = bldf(P.cinv, ypl, cob); }
-                        if (MODE == S2) { ga[t] = (float)__builtin_bit_cast(fg_t, bld(P.fg1, yfg, cob + 256u)).x; }
+                        if (MODE == S1) { ga[t] = bldf(P.stat, ypl, cob); gb[t] = bldf(P.stat, ypl, P.cinvo + cob); }
+                        if (MODE == S2) { ga[t] = (float)__builtin_bit_cast(fg_t, bld(P.img, yfg, P.fg1o + cob + 256u)).x; }
                     }
 #pragma unroll
                     for (int t = 0; t < PB; ++t) {
@@ -771,7 +806,11 @@ static int launch_carry(const v2::Launch& L, int nslices, int nviews, hipStream_
 template <int MODE>
 static int launch_walk(const v2::Launch& L, int nslices, int nviews, hipStream_t st) {
     const v2::Args& a = L.v[0];
-    hipLaunchKernelGGL(v2::k_v2_walk<MODE>, dim3(a.nstrips, nslices, nviews), dim3(v2::NTHREADS), 0, st, L);
+    v2::Launch LL = L;
+    LL.nslices = nslices;
+    LL.nviews = nviews;
+    hipLaunchKernelGGL(v2::k_v2_walk<MODE>, dim3((unsigned)(a.nstrips * nslices * nviews)), dim3(v2::NTHREADS),
+                       0, st, LL);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
