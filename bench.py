@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--workload", default="kitti", choices=["tsukuba", "kitti", "motorcycle", "4k"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slices-in-flight", type=int, default=None)
+    ap.add_argument("--pipeline", type=int, default=None, help="slice sub-chunks pipelined over streams")
     args = ap.parse_args()
 
     import numpy as np
@@ -62,6 +63,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     smx.lib()  # fail loudly if the HIP extension is missing
+    if args.pipeline is not None:
+        smx.lib().smx_set_agg_pipeline(args.pipeline)
     w, h, D = synth.SHAPES[args.workload]
     seed = synth.SEEDS.get(args.workload, 1)
     Il, Ir = synth.gen_pair(w, h, D, seed)
@@ -112,6 +115,20 @@ def main():
     cells_per_call = 2.0 * w * h * local_slices   # left + right volume
     achieved = ALGO_BYTES_PER_CELL * cells_per_call / agg_avg_s / 1e9 if agg_avg_s > 0 else 0.0
 
+    # HBM bytes of one aggregation call from the committed PMC profile of this same command
+    # (tools/pmc.sh + tools/traffic.py; FETCH_SIZE/WRITE_SIZE in separate passes, gfx950 x2 fetch
+    # correction calibrated on a kernel with a known byte count).  Only valid for the profiled config.
+    traffic = None
+    traffic_src = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if world == 1 and args.workload == "kitti" and pipe.slices_in_flight == D and os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            traffic = float(tj["aggregation_call_hbm_bytes"])
+            traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+        except (ValueError, KeyError):
+            traffic = None
+
     result = {
         "metric": "disparity MPix/s (stereo pair -> L+R disparity + occlusion-filled map)",
         "value": (w * h * args.steps) / dt / 1e6,
@@ -136,7 +153,8 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "avg_launch_ms": agg_avg_s * 1e3,
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * cells_per_call,
         },

@@ -162,6 +162,9 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
  * one the last smx_dev_aggregate_wta call on this thread used (1 or 2). */
 int smx_set_agg_path(int path);
 int smx_last_agg_path(void);
+/* Number of slice sub-chunks the fused path software-pipelines over its internal streams
+ * (default 1 = everything on the caller's stream; 2-8 measured slower on one GPU).  Process-wide. */
+int smx_set_agg_pipeline(int subchunks);
 
 /* winner_take_all.cuh (live WTA = dispSelectOnGPU, guidedFilter.cu:403-411), packed form. */
 int smx_dev_init_keys(uint64_t* d_keys, int64_t n, void* stream);

@@ -19,6 +19,7 @@ static thread_local int g_last_path = 0;
 
 // smx_agg_v2.hip
 bool v2_supported(const smx_params* p);
+void v2_set_pipeline(int subchunks);
 size_t v2_workspace_bytes(int w, int h, int R, int nslices);
 int aggregate_v2(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                  const uint8_t* const* d_other, int w, int h, const int* dmin, int s_begin, int s_end,
@@ -136,6 +137,11 @@ int smx_set_agg_path(int path) {
 }
 
 int smx_last_agg_path(void) { return g_last_path; }
+
+int smx_set_agg_pipeline(int subchunks) {
+    v2_set_pipeline(subchunks);
+    return SMX_OK;
+}
 
 int smx_dev_init_keys(uint64_t* d_keys, int64_t n, void* stream) {
     SMX_ARG(d_keys && n > 0);

@@ -223,6 +223,24 @@ def test_device_pipeline_tsukuba_fused_cost(tsukuba_gray, tsukuba_oracle, path):
         _eq(r[k], tsukuba_oracle[k], k)
 
 
+@pytest.mark.parametrize("subchunks", [1, 2, 7])
+def test_stream_pipelined_subchunks_give_identical_results(orc, subchunks):
+    """The fused path pipelines slice sub-chunks over internal streams (smx_set_agg_pipeline)."""
+    w, h, D = 300, 200, 70
+    rng = np.random.default_rng(99)
+    base = rng.integers(0, 256, size=(h, w + D), dtype=np.uint8)
+    Il = np.ascontiguousarray(base[:, :w])
+    Ir = np.ascontiguousarray(base[:, 20:20 + w])
+    want = orc.stereo_pair(Il, Ir, D)
+    smx.lib().smx_set_agg_pipeline(subchunks)
+    try:
+        r = _device_pair(Il, Ir, D)
+    finally:
+        smx.lib().smx_set_agg_pipeline(1)
+    for k in KEYS:
+        _eq(r[k], want[k], k)
+
+
 def test_default_path_is_the_fused_one(tsukuba_gray):
     import torch
     from stereo_matching_cuda_amd.device import PairPipeline
