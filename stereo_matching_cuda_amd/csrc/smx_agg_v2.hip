@@ -547,27 +547,56 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
         __syncthreads();
         // ---------------- phase C: LANE = COLUMN, R -> S in place ------------------------------
         if (ci < 2) {
+            // 64 dependent adds per column in batches of 8 rows.  Where registers allow (not in S1,
+            // which would spill) the LDS reads of the next batch are issued before the adds of the
+            // current one, so the chain does not wait for an LDS round trip per batch.
+            constexpr int CBT = 8;
+            constexpr bool AHEAD = MODE != S1;
+            float* colp = &ring[ci][0][cj];
             int rr = ring_row(y0);
             int r = 0;
-            for (; r + 8 <= rows; r += 8) {
-                float v[8];
-                int ro[8];
+            float cur[CBT], nxt[CBT];
+            int ro[CBT], rn[CBT];
+            if (AHEAD && rows >= CBT) {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    ro[t] = rr;
-                    v[t] = ring[ci][rr][cj];
+                for (int t = 0; t < CBT; ++t) {
+                    ro[t] = rr * PITCH;
+                    cur[t] = colp[ro[t]];
                     rr = (rr + 1 == RR) ? 0 : rr + 1;
                 }
+            }
+            for (; r + CBT <= rows; r += CBT) {
+                const bool more = AHEAD && (r + 2 * CBT <= rows);
+                if (!AHEAD) {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    S = v[t] + S;
-                    ring[ci][ro[t]][cj] = S;
+                    for (int t = 0; t < CBT; ++t) {
+                        ro[t] = rr * PITCH;
+                        cur[t] = colp[ro[t]];
+                        rr = (rr + 1 == RR) ? 0 : rr + 1;
+                    }
+                }
+                if (more) {
+#pragma unroll
+                    for (int t = 0; t < CBT; ++t) {
+                        rn[t] = rr * PITCH;
+                        nxt[t] = colp[rn[t]];
+                        rr = (rr + 1 == RR) ? 0 : rr + 1;
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < CBT; ++t) {
+                    S = cur[t] + S;
+                    colp[ro[t]] = S;
+                }
+                if (more) {
+#pragma unroll
+                    for (int t = 0; t < CBT; ++t) { cur[t] = nxt[t]; ro[t] = rn[t]; }
                 }
             }
             for (; r < rows; ++r) {
-                float v = ring[ci][rr][cj];
+                float v = colp[rr * PITCH];
                 S = v + S;
-                ring[ci][rr][cj] = S;
+                colp[rr * PITCH] = S;
                 rr = (rr + 1 == RR) ? 0 : rr + 1;
             }
         }
