@@ -25,10 +25,17 @@ def keys_to_signed(keys):
 
 
 def allreduce_min_keys_(keys_i64, group=None):
-    """In-place MIN all-reduce of packed keys stored as int64 bit patterns (u64 order)."""
+    """In-place MIN all-reduce of packed keys stored as int64 bit patterns (u64 order).
+    Device tensors go through RCCL (backend "nccl"); with a gloo group (CPU rehearsal of the N>1
+    path, several ranks sharing one GPU) they are staged through host memory."""
     keys_i64.bitwise_xor_(_I64_MIN)
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(keys_i64, op=dist.ReduceOp.MIN, group=group)
+        if keys_i64.is_cuda and dist.get_backend(group) == "gloo":
+            host = keys_i64.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MIN, group=group)
+            keys_i64.copy_(host)
+        else:
+            dist.all_reduce(keys_i64, op=dist.ReduceOp.MIN, group=group)
     keys_i64.bitwise_xor_(_I64_MIN)
     return keys_i64
 

@@ -352,3 +352,45 @@ def test_pair_motorcycle_shape_properties():
     r = pipe.results()
     for k in KEYS[2:]:
         _eq(r[k], ref[k], k)
+
+
+# ---------------------------------------------------------------------------------------------
+# N > 1 end to end on one GPU: two processes, each aggregating its disparity shard with the HIP
+# kernels on cuda:0, merged by the product's all-reduce (gloo here; RCCL on a multi-GPU node).
+# ---------------------------------------------------------------------------------------------
+def _rank_worker(rank, world, port, Il, Ir, D, out_dir):
+    import os
+    import torch
+    import torch.distributed as dist
+    from stereo_matching_cuda_amd.sharded import ShardedPair
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        h, w = Il.shape
+        sp = ShardedPair(w, h, D, rank=rank, world=world, device="cuda:0")
+        pipe = sp.run(torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda())
+        r = pipe.results()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{k: r[k] for k in KEYS[2:]})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pair_two_processes_on_one_gpu(orc, tmp_path, world):
+    import socket
+    import torch.multiprocessing as mp
+    w, h, D = 200, 130, 37
+    rng = np.random.default_rng(5)
+    base = rng.integers(0, 256, size=(h, w + D), dtype=np.uint8)
+    Il = np.ascontiguousarray(base[:, :w])
+    Ir = np.ascontiguousarray(base[:, 11:11 + w])
+    want = orc.stereo_pair(Il, Ir, D)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_worker, args=(world, port, Il, Ir, D, str(tmp_path)), nprocs=world, join=True)
+    for rank in range(world):
+        got = np.load(tmp_path / f"rank{rank}.npz")
+        for k in KEYS[2:]:
+            _eq(got[k], want[k], f"rank{rank} {k}")
