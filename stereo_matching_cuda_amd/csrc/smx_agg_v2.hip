@@ -547,53 +547,49 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
         __syncthreads();
         // ---------------- phase C: LANE = COLUMN, R -> S in place ------------------------------
         if (ci < 2) {
-            // 64 dependent adds per column in batches of 8 rows.  Where registers allow (not in S1,
-            // which would spill) the LDS reads of the next batch are issued before the adds of the
-            // current one, so the chain does not wait for an LDS round trip per batch.
+            // 64 dependent adds per column in batches of 8 rows.  y0 and RR are multiples of 8, so a
+            // batch never straddles the ring wrap: one base address per batch, immediate offsets for
+            // its rows.  Where registers allow (not in S1, which would spill) two batches ping-pong:
+            // the LDS reads of the next batch are issued before the adds of the current one.
             constexpr int CBT = 8;
             constexpr bool AHEAD = MODE != S1;
             float* colp = &ring[ci][0][cj];
             int rr = ring_row(y0);
-            int r = 0;
-            float cur[CBT], nxt[CBT];
-            int ro[CBT], rn[CBT];
-            if (AHEAD && rows >= CBT) {
+            const int nb = rows / CBT;
+            auto next_batch = [&]() {
+                float* bp = colp + rr * PITCH;
+                rr = (rr + CBT >= RR) ? rr + CBT - RR : rr + CBT;
+                return bp;
+            };
+            auto rd = [&](float* bp, float (&v)[CBT]) {
+#pragma unroll
+                for (int t = 0; t < CBT; ++t) v[t] = bp[t * PITCH];
+            };
+            auto acc = [&](float* bp, const float (&v)[CBT]) {
 #pragma unroll
                 for (int t = 0; t < CBT; ++t) {
-                    ro[t] = rr * PITCH;
-                    cur[t] = colp[ro[t]];
-                    rr = (rr + 1 == RR) ? 0 : rr + 1;
+                    S = v[t] + S;
+                    bp[t * PITCH] = S;
+                }
+            };
+            float va[CBT], vb[CBT];
+            if (AHEAD) {
+                float *pa = nullptr, *pb = nullptr;
+                if (nb > 0) { pa = next_batch(); rd(pa, va); }
+                for (int i = 0; i < nb; i += 2) {
+                    if (i + 1 < nb) { pb = next_batch(); rd(pb, vb); }
+                    acc(pa, va);
+                    if (i + 2 < nb) { pa = next_batch(); rd(pa, va); }
+                    if (i + 1 < nb) acc(pb, vb);
+                }
+            } else {
+                for (int i = 0; i < nb; ++i) {
+                    float* pa = next_batch();
+                    rd(pa, va);
+                    acc(pa, va);
                 }
             }
-            for (; r + CBT <= rows; r += CBT) {
-                const bool more = AHEAD && (r + 2 * CBT <= rows);
-                if (!AHEAD) {
-#pragma unroll
-                    for (int t = 0; t < CBT; ++t) {
-                        ro[t] = rr * PITCH;
-                        cur[t] = colp[ro[t]];
-                        rr = (rr + 1 == RR) ? 0 : rr + 1;
-                    }
-                }
-                if (more) {
-#pragma unroll
-                    for (int t = 0; t < CBT; ++t) {
-                        rn[t] = rr * PITCH;
-                        nxt[t] = colp[rn[t]];
-                        rr = (rr + 1 == RR) ? 0 : rr + 1;
-                    }
-                }
-#pragma unroll
-                for (int t = 0; t < CBT; ++t) {
-                    S = cur[t] + S;
-                    colp[ro[t]] = S;
-                }
-                if (more) {
-#pragma unroll
-                    for (int t = 0; t < CBT; ++t) { cur[t] = nxt[t]; ro[t] = rn[t]; }
-                }
-            }
-            for (; r < rows; ++r) {
+            for (int r = nb * CBT; r < rows; ++r) {
                 float v = colp[rr * PITCH];
                 S = v + S;
                 colp[rr * PITCH] = S;
@@ -656,6 +652,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
                                 float m1 = div_small_int(val1, area, rarea);
                                 const bool tiny = (fabsf(val0) < 0x1p-100f) || (fabsf(val1) < 0x1p-100f);
                                 if (__any(tiny)) {
+                                    // rare (window sums that are exactly 0 or denormal-small).  The empty
+                                    // asm keeps this a real wave-uniform branch: without it hipcc
+                                    // if-converts and runs both IEEE divisions for every column.
+                                    asm volatile("; exact-division slow path");
                                     m0 = 1.0f * val0 / area;
                                     m1 = 1.0f * val1 / area;
                                 }
