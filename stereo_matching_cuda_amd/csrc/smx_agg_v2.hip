@@ -171,18 +171,32 @@ __device__ __forceinline__ void cost_pair(fg_t q1, fg_t q2, const CostConst& cc,
 // (their values are never accumulated).
 template <int MODE>
 struct Source {
-    const fg_t *fg1, *fg2;
-    const float *sa, *sb;
-    int hp, w, d;
+    rsrc_t img, ra, rb;          // both image planes; S2: this slice's a / b planes
+    unsigned fg1o, fg2o;         // byte offsets of this view's / the other view's plane inside img
+    unsigned yfg, ypl;           // lane byte offsets in image planes / a,b planes
+    int w, d;
     CostConst cc;
     __device__ __forceinline__ Source(const Args& a, int slice, int y) {
-        hp = a.hp; w = a.w; d = a.d0 + slice; cc = a.cc;
-        fg1 = a.FG1 + blane(y, a.w + 2); fg2 = a.FG2 + blane(y, a.w + 2);
+        w = a.w; d = a.d0 + slice; cc = a.cc;
         const size_t plane = (size_t)a.w * a.hp;
-        sa = MODE == S2 ? a.srcA + (size_t)slice * plane + blane(y, a.w) : nullptr;
-        sb = MODE == S2 ? a.srcB + (size_t)slice * plane + blane(y, a.w) : nullptr;
+        const size_t fgbytes = (size_t)(a.w + 2) * a.hp * sizeof(fg_t);
+        const fg_t* lo = a.FG1 < a.FG2 ? a.FG1 : a.FG2;
+        const fg_t* hi = a.FG1 < a.FG2 ? a.FG2 : a.FG1;
+        if (MODE == S1) {
+            img = mk_rsrc(lo, (size_t)((const char*)hi - (const char*)lo) + fgbytes);
+            fg1o = (unsigned)((const char*)a.FG1 - (const char*)lo);
+            fg2o = (unsigned)((const char*)a.FG2 - (const char*)lo);
+        } else {
+            img = mk_rsrc(a.FG1, fgbytes);
+            fg1o = 0; fg2o = 0;
+        }
+        ra = mk_rsrc(MODE == S2 ? a.srcA + (size_t)slice * plane : (const float*)a.FG1, plane * sizeof(float));
+        rb = mk_rsrc(MODE == S2 ? a.srcB + (size_t)slice * plane : (const float*)a.FG1, plane * sizeof(float));
+        yfg = blane(y, a.w + 2) * 4u;
+        ypl = blane(y, a.w) * 4u;
     }
-    // raw operands of NB columns (issue only; nothing waits here)
+    // raw operands of NB columns (issue only; nothing waits here).  Columns >= w read past the
+    // descriptor or a neighbouring column; their values are never accumulated.
     template <int NB>
     struct Raw {
         uint32_t a[NB], b[NB];
@@ -191,19 +205,18 @@ struct Source {
     __device__ __forceinline__ void fetch(int c0, Raw<NB>& r) const {
 #pragma unroll
         for (int t = 0; t < NB; ++t) {
-            int c = c0 + t;
-            c = c < 0 ? 0 : (c >= w ? w - 1 : c);
+            const int c = c0 + t;
             if (MODE == GUID) {
-                r.a[t] = __builtin_bit_cast(uint32_t, fg1[bcol(c + 1)]);
+                r.a[t] = bld(img, yfg, (unsigned)(c + 1) * 256u);
                 r.b[t] = 0;
             } else if (MODE == S1) {
                 int xx = c + d;
                 xx = xx < -1 ? -1 : (xx > w ? w : xx);  // sentinel columns at -1 and w
-                r.a[t] = __builtin_bit_cast(uint32_t, fg1[bcol(c + 1)]);
-                r.b[t] = __builtin_bit_cast(uint32_t, fg2[bcol(xx + 1)]);
+                r.a[t] = bld(img, yfg, fg1o + (unsigned)(c + 1) * 256u);
+                r.b[t] = bld(img, yfg, fg2o + (unsigned)(xx + 1) * 256u);
             } else {
-                r.a[t] = __builtin_bit_cast(uint32_t, sa[bcol(c)]);
-                r.b[t] = __builtin_bit_cast(uint32_t, sb[bcol(c)]);
+                r.a[t] = bld(ra, ypl, (unsigned)c * 256u);
+                r.b[t] = bld(rb, ypl, (unsigned)c * 256u);
             }
         }
     }
