@@ -199,7 +199,8 @@ def pack_keys(best, slices):
     neg = (u & np.uint32(0x80000000)) != 0
     o = np.where(neg, ~u, u | np.uint32(0x80000000)).astype(np.uint64)
     lo = (np.uint64(0xFFFFFFFF) - np.asarray(slices).astype(np.uint64))
-    return (o << np.uint64(32)) | lo
+    keys = (o << np.uint64(32)) | lo
+    return np.where(np.isnan(b), np.uint64(0xFFFFFFFFFFFFFFFF), keys)
 
 
 def unpack_keys(keys):

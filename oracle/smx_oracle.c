@@ -333,6 +333,7 @@ ORC_API void orc_stereo_pair(const orc_params* P, const uint8_t* Il, const uint8
  * ord: monotone f32 -> u32 map (-0 canonicalised to +0). */
 ORC_API uint64_t orc_pack_key(float best, uint32_t slice) {
     uint32_t u;
+    if (best != best) return ~(uint64_t)0; /* NaN never wins (`best >= q` is false) */
     if (best == 0.0f) best = 0.0f; /* -0 -> +0 */
     memcpy(&u, &best, 4);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);

@@ -50,7 +50,10 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // ---- packed WTA key ---------------------------------------------------------------------
 // key = ord(cost) << 32 | (0xFFFFFFFF - slice); ord = monotone f32 -> u32 (-0 folded to +0).
+// A NaN cost (only from degenerate parameters, e.g. var + eps == 0) never wins, like the reference's
+// `best >= q`, which is false for NaN: it maps to the identity key.
 __host__ __device__ inline uint64_t pack_key(float cost, uint32_t slice) {
+    if (cost != cost) return ~0ull;
     if (cost == 0.0f) cost = 0.0f;
     uint32_t u = __builtin_bit_cast(uint32_t, cost);
     u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);

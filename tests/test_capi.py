@@ -57,6 +57,15 @@ def test_pack_key_host_matches_oracle(lib, orc):
             assert sl.value == s and np.float32(c.value) == (np.float32(0) if v == 0 else v)
 
 
+def test_nan_cost_never_wins(lib, orc):
+    nan_pos = np.float32(np.nan)
+    nan_neg = np.array([0xFFC00000], np.uint32).view(np.float32)[0]
+    for v in (nan_pos, nan_neg):
+        assert lib.smx_pack_key(float(v), 3) == 0xFFFFFFFFFFFFFFFF
+        assert int(orc.lib().orc_pack_key(float(v), 3)) == 0xFFFFFFFFFFFFFFFF
+    assert int(orc.pack_keys(np.array([nan_neg, 1.0], np.float32), [3, 4])[0]) == 0xFFFFFFFFFFFFFFFF
+
+
 def test_argument_errors_do_not_need_a_gpu(lib):
     p = smx.default_params()
     rc = lib.smx_compute_cost(C.byref(p), None, None, None, 4, 4, 4, 4, 1, 0)
