@@ -394,10 +394,25 @@ struct RawRow {
     uint32_t u[MODE == GUID ? 1 : 2][SUBW];
 };
 
-template <int MODE>
+// FAST: every column of the sub-strip (and, for S1, its disparity-shifted partner) is inside the
+// image, so the byte offsets are base + t*256 with t a compile-time constant: they fold into the
+// instructions' immediate offsets and the 13 loads cost no scalar arithmetic at all.
+template <int MODE, bool FAST>
 __device__ __forceinline__ void raw_load(const Planes& P, int w, int d, unsigned yfg, unsigned ypl, int c0,
                                          RawRow<MODE>& r) {
     // yfg / ypl: lane byte offsets blane(y, w + 2) * 4 (image planes) and blane(y, w) * 4 (a, b)
+    if (FAST) {
+        const unsigned o1 = P.fg1o + (unsigned)(c0 + 1) * 256u;
+        const unsigned o2 = P.fg2o + (unsigned)(c0 + d + 1) * 256u;
+        const unsigned oa = (unsigned)c0 * 256u;
+#pragma unroll
+        for (int t = 0; t < SUBW; ++t) {
+            if (MODE == GUID) r.u[0][t] = bld(P.img, yfg, o1 + t * 256u);
+            if (MODE == S1) { r.u[0][t] = bld(P.img, yfg, o1 + t * 256u); r.u[1][t] = bld(P.img, yfg, o2 + t * 256u); }
+            if (MODE == S2) { r.u[0][t] = bld(P.srcA, ypl, oa + t * 256u); r.u[1][t] = bld(P.srcB, ypl, oa + t * 256u); }
+        }
+        return;
+    }
     if (MODE == GUID) {
 #pragma unroll
         for (int t = 0; t < SUBW; ++t) {
@@ -500,6 +515,10 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
     const int j0 = wave * SUBW;
     const int cbeg_ = cs_ + j0;
 
+    // sub-strip (and for S1 its shifted partner window) entirely inside the image: straight-line
+    // phase R with immediate offsets (wave-uniform)
+    const bool fastR = (cbeg_ >= 0) && (cbeg_ + SUBW <= w) &&
+                       (MODE != S1 || ((cbeg_ + dsl >= -1) && (cbeg_ + SUBW - 1 + dsl <= w)));
     // operands of phase R are loaded one band ahead (their latency hides behind phase B)
     RawRow<MODE> raw;
     float cin0, cin1;
@@ -507,7 +526,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
         const int y = min(lane, h - 1);
         cin0 = bldf(P.car, (unsigned)y * 4u, 0);
         cin1 = bldf(P.car, (unsigned)y * 4u, P.car1o);
-        raw_load<MODE>(P, w, dsl, blane(y, w + 2) * 4u, blane(y, w) * 4u, cbeg_, raw);
+        if (fastR) raw_load<MODE, true>(P, w, dsl, blane(y, w + 2) * 4u, blane(y, w) * 4u, cbeg_, raw);
+        else raw_load<MODE, false>(P, w, dsl, blane(y, w + 2) * 4u, blane(y, w) * 4u, cbeg_, raw);
     }
 
     for (int b = 0; b < nbands; ++b) {
@@ -525,16 +545,28 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
             float* r0 = &ring[0][rr][j0];
             float* r1 = &ring[1][rr][j0];
             float acc0 = cin0, acc1 = cin1;
+            if (fastR) {
 #pragma unroll
-            for (int t = 0; t < SUBW; ++t) {
-                const int c = cbeg + t;
-                if (c >= 0 && c < w) {
+                for (int t = 0; t < SUBW; ++t) {
                     float v0, v1;
                     raw_eval<MODE>(raw, t, cc, v0, v1);
                     acc0 = v0 + acc0;
                     acc1 = v1 + acc1;
                     r0[t] = acc0;
                     r1[t] = acc1;
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < SUBW; ++t) {
+                    const int c = cbeg + t;
+                    if (c >= 0 && c < w) {
+                        float v0, v1;
+                        raw_eval<MODE>(raw, t, cc, v0, v1);
+                        acc0 = v0 + acc0;
+                        acc1 = v1 + acc1;
+                        r0[t] = acc0;
+                        r1[t] = acc1;
+                    }
                 }
             }
         }
@@ -614,7 +646,8 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
             const int y = min(y0 + BH + lane, h - 1);
             cin0 = bldf(P.car, (unsigned)y * 4u, 0);
             cin1 = bldf(P.car, (unsigned)y * 4u, P.car1o);
-            raw_load<MODE>(P, w, dsl, blane(y, w + 2) * 4u, blane(y, w) * 4u, cbeg, raw);
+            if (fastR) raw_load<MODE, true>(P, w, dsl, blane(y, w + 2) * 4u, blane(y, w) * 4u, cbeg, raw);
+            else raw_load<MODE, false>(P, w, dsl, blane(y, w + 2) * 4u, blane(y, w) * 4u, cbeg, raw);
         }
         __syncthreads();
         // ---------------- phase B: LANE = ROW, box means + stage arithmetic --------------------
