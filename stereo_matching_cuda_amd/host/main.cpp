@@ -1,10 +1,14 @@
-// main.cpp -- drop-in for the reference's entry point (stereo_matching_cuda/main.cu:37-214):
-// same flow, same progress lines, same 12 output images, every stage through the reference-named
-// host functions of this directory (which forward to the HIP kernels behind include/smx.h).
+// main.cpp -- drop-in for the reference's entry point (stereo_matching_cuda/main.cu:37-214).
+// Same stage order, same progress lines on stdout, same 12 output images, and every stage goes
+// through the reference-named host functions of this directory (which forward to the HIP kernels
+// behind include/smx.h).  The code itself is organised differently: buffers are std::vectors, the
+// outputs are table driven, and the image normaliser is a two-pass restatement of write_mat.
 //
 //   smx_main                         reference behaviour: ./data/tsukuba0.png, ./data/tsukuba1.png,
 //                                    D_MIN..D_MAX from the macros, outputs into ./data/
 //   smx_main L.png R.png [dmin dmax [outdir]]
+#include <vector>
+
 #include "costVolume.cuh"
 #include "filter.cuh"
 #include "guidedFilter.cuh"
@@ -14,117 +18,123 @@
 #include "rgb_to_grayscale.cuh"
 #include "winner_take_all.cuh"
 
-using namespace std;
+namespace {
 
-// main.cu:13-35
-void write_mat(float* mat, const char* filename, int w, int h, int start) {
-    unsigned char* matchar = (unsigned char*)malloc((size_t)w * h);
-    memset(matchar, 0, (size_t)w * h);
-    float max = -150000000.0f;
-    float min = 150000000.0f;
-    for (int i = start; i < start + w * h; i++) {
-        if (mat[i] > max) {
-            max = mat[i];
-        } else if (mat[i] <= min) {
-            min = mat[i];
-        }
+// Float map -> 8-bit image exactly like the reference's write_mat (main.cu:13-35): the maximum is
+// the true maximum, but the minimum only considers elements that did NOT raise the running maximum
+// at their position (the reference's `else if`); values map through (v - min) * 255 / (max - min)
+// in f32 and are truncated.
+std::vector<unsigned char> normalise_like_reference(const float* v, size_t n) {
+    float hi = -150000000.0f, lo = 150000000.0f;
+    for (size_t i = 0; i < n; ++i) {
+        const bool raises_max = v[i] > hi;
+        if (raises_max) hi = v[i];
+        if (!raises_max && v[i] <= lo) lo = v[i];
     }
-    for (int i = 0; i < w * h; i++) {
-        int c = (mat[i + start] - min) * 255.0f / (max - min);
-        matchar[i] = (unsigned char)c;
+    std::vector<unsigned char> out(n);
+    const float span = hi - lo;
+    for (size_t i = 0; i < n; ++i) {
+        const int level = (v[i] - lo) * 255.0f / span;
+        out[i] = (unsigned char)level;
     }
-    smx_png_write(filename, w, h, 1, matchar);
-    free(matchar);
+    return out;
 }
 
+struct Pair {
+    int w = 0, h = 0;
+    unsigned char* rgb[2] = {nullptr, nullptr};
+    int channels[2] = {0, 0};
+};
+
+bool load_pair(const std::string& left, const std::string& right, Pair& p) {
+    int w2 = 0, h2 = 0;
+    p.rgb[0] = smx_png_load(left.c_str(), &p.w, &p.h, &p.channels[0]);
+    p.rgb[1] = smx_png_load(right.c_str(), &w2, &h2, &p.channels[1]);
+    return p.rgb[0] && p.rgb[1] && p.channels[0] >= 3 && p.channels[1] >= 3 && p.w == w2 && p.h == h2;
+}
+
+}  // namespace
+
 int main(int argc, char** argv) {
-    bool host_compare = false;
-    printf("Starting...\n");
+    const bool host_compare = false;          // main.cu:40 (the reference hard-codes false too)
+    std::printf("Starting...\n");
     if (smx_device_count() < 1) {
-        fprintf(stderr, "no HIP device available\n");
+        std::fprintf(stderr, "no HIP device available\n");
         return 1;
     }
-    printf("Using Device %d: %s\n", 0, smx_version());
+    std::printf("Using Device %d: %s\n", 0, smx_version());
 
-    string left = "./data/tsukuba0.png", right = "./data/tsukuba1.png", outdir = "./data";
+    std::string left = "./data/tsukuba0.png", right = "./data/tsukuba1.png", outdir = "./data";
     if (argc >= 3) { left = argv[1]; right = argv[2]; }
-    if (argc >= 5) { smx_config().d_min = atoi(argv[3]); smx_config().d_max = atoi(argv[4]); }
+    if (argc >= 5) { smx_config().d_min = std::atoi(argv[3]); smx_config().d_max = std::atoi(argv[4]); }
     if (argc >= 6) outdir = argv[5];
-    const int d_min = smx_config().d_min, d_max = smx_config().d_max;
+    const int d_lo = smx_config().d_min, d_hi = smx_config().d_max;
 
-    std::clock_t start = std::clock();
-    int w1, h1, ch1, w2, h2, ch2;
-    unsigned char* data1 = smx_png_load(left.c_str(), &w1, &h1, &ch1);
-    unsigned char* data2 = smx_png_load(right.c_str(), &w2, &h2, &ch2);
-    if (!data1 || !data2 || ch1 < 3 || ch2 < 3 || w1 != w2 || h1 != h2) {
-        fprintf(stderr, "cannot load an RGB pair of equal size from %s / %s\n", left.c_str(), right.c_str());
+    const std::clock_t t_begin = std::clock();
+    Pair in;
+    if (!load_pair(left, right, in)) {
+        std::fprintf(stderr, "cannot load an RGB pair of equal size from %s / %s\n", left.c_str(),
+                     right.c_str());
         return 1;
     }
-    int n1 = w1 * h1, n2 = w2 * h2;
-    cout << "Resolution : " << w1 << "x" << h1 << endl;
-    cout << "RGB to grayscale ..." << endl;
-    unsigned char* I_l = rgb_to_grayscale(data1, n1, ch1, host_compare);
-    unsigned char* I_r = rgb_to_grayscale(data2, n2, ch2, host_compare);
+    const int w = in.w, h = in.h, n = w * h;
+    std::cout << "Resolution : " << w << "x" << h << std::endl;
 
-    int size_d = d_max - d_min + 1;
-    size_t totalSize1 = (size_t)n1 * size_d, totalSize2 = (size_t)n2 * size_d;
-    float* costl = (float*)malloc(sizeof(float) * totalSize1);
-    float* costr = (float*)malloc(sizeof(float) * totalSize2);
-    cout << "Cost Volume ..." << endl;
-    const int dminl = d_min;
-    compute_cost(I_l, I_r, costl, w1, w2, h1, h2, dminl, host_compare);
-    const int dminr = -d_max;
-    compute_cost(I_r, I_l, costr, w2, w1, h2, h1, dminr, host_compare);
+    std::cout << "RGB to grayscale ..." << std::endl;
+    unsigned char* gray[2] = {rgb_to_grayscale(in.rgb[0], n, in.channels[0], host_compare),
+                              rgb_to_grayscale(in.rgb[1], n, in.channels[1], host_compare)};
 
-    unsigned char* mean1 = (unsigned char*)malloc(n1);
-    unsigned char* mean2 = (unsigned char*)malloc(n2);
-    float* best_costl = (float*)malloc(n1 * sizeof(float));
-    float* best_costr = (float*)malloc(n2 * sizeof(float));
-    memset(best_costl, 9999999.0f, n1 * sizeof(float));   // main.cu:112: every byte 0x7F
-    memset(best_costr, 9999999.0f, n2 * sizeof(float));
-    float* dmapl = (float*)malloc(n1 * sizeof(float));
-    float* dmapr = (float*)malloc(n2 * sizeof(float));
-    memset(dmapl, 0, n1 * sizeof(float));
-    memset(dmapr, 0, n2 * sizeof(float));
-    unsigned char* dmaplChar = (unsigned char*)calloc(n1, 1);
-    unsigned char* dmaprChar = (unsigned char*)calloc(n2, 1);
+    // left volume: labels d_lo .. d_hi; right volume: labels -d_hi .. -d_lo   (main.cu:79-82)
+    const int size_d = d_hi - d_lo + 1;
+    const int dmin[2] = {d_lo, -d_hi};
+    std::vector<float> cost[2] = {std::vector<float>((size_t)n * size_d), std::vector<float>((size_t)n * size_d)};
+    std::cout << "Cost Volume ..." << std::endl;
+    compute_cost(gray[0], gray[1], cost[0].data(), w, w, h, h, dmin[0], host_compare);
+    compute_cost(gray[1], gray[0], cost[1].data(), w, w, h, h, dmin[1], host_compare);
 
-    cout << "guided filter ..." << endl;
-    compute_guided_filter(I_l, costl, best_costl, dmapl, mean1, w1, h1, size_d, dminl, host_compare);
-    compute_guided_filter(I_r, costr, best_costr, dmapr, mean2, w2, h2, size_d, dminr, host_compare);
+    // WTA presets of main.cu:112-118: memset(best, 9999999.0f) stores byte 0x7F everywhere
+    std::vector<float> best[2], dmap[2];
+    std::vector<unsigned char> mean[2], unused_u8[2];
+    for (int v = 0; v < 2; ++v) {
+        best[v].resize(n);
+        std::memset(best[v].data(), 0x7F, sizeof(float) * n);
+        dmap[v].assign(n, 0.0f);
+        mean[v].assign(n, 0);
+        unused_u8[v].assign(n, 0);
+    }
+    std::cout << "guided filter ..." << std::endl;
+    for (int v = 0; v < 2; ++v)
+        compute_guided_filter(gray[v], cost[v].data(), best[v].data(), dmap[v].data(), mean[v].data(), w, h,
+                              size_d, dmin[v], host_compare);
+    std::cout << "guided filter ok" << std::endl;
 
-    float* occlusion = (float*)malloc(n1 * sizeof(float));
-    memcpy(occlusion, dmapl, n1 * sizeof(float));
-    float* occlusion_filled = (float*)malloc(n1 * sizeof(float));
-    cout << "guided filter ok" << endl;
+    // left-right check on a copy of the left map, then scan-line filling on a copy of that
+    std::vector<float> occlusion(dmap[0]);
+    detect_occlusion(occlusion.data(), dmap[1].data(), dmin[0] - 100, unused_u8[0].data(),
+                     unused_u8[1].data(), w, h);                                   // main.cu:149-150
+    std::vector<float> filled(occlusion);
+    fill_occlusion(filled.data(), w, h, (float)d_lo);                              // main.cu:154-155
+    const double duration = (std::clock() - t_begin) / (double)CLOCKS_PER_SEC;
 
-    const int dOcclusion = (dminl - 100);
-    detect_occlusion(occlusion, dmapr, dOcclusion, dmaplChar, dmaprChar, w1, h1);
-    memcpy(occlusion_filled, occlusion, n1 * sizeof(float));
-    int vMin = d_min;
-    fill_occlusion(occlusion_filled, w1, h1, vMin);
-    double duration = (std::clock() - start) / (double)CLOCKS_PER_SEC;
-
-    cout << "writing images ..." << endl;
-    auto out = [&](const char* name) { return outdir + "/" + name; };
-    smx_png_write(out("image_left.png").c_str(), w1, h1, 1, I_l);
-    smx_png_write(out("image_right.png").c_str(), w2, h2, 1, I_r);
-    smx_png_write(out("image_mean_left.png").c_str(), w1, h1, 1, mean1);
-    smx_png_write(out("image_mean_right.png").c_str(), w2, h2, 1, mean2);
-    write_mat(best_costl, out("best_costl.png").c_str(), w1, h1, 0);
-    write_mat(best_costr, out("best_costr.png").c_str(), w2, h2, 0);
-    // the reference names these after its default range (cost_lminus15.png); same names kept
-    write_mat(costl, out("cost_lminus15.png").c_str(), w1, h1, 0);
-    write_mat(costr, out("cost_rminus15.png").c_str(), w2, h2, 0);
-    write_mat(occlusion, out("occlu_mapl.png").c_str(), w1, h1, 0);
-    write_mat(dmapl, out("disparity_mapl.png").c_str(), w1, h1, 0);
-    write_mat(dmapr, out("disparity_mapr.png").c_str(), w2, h2, 0);
-    write_mat(occlusion_filled, out("occlu_mapl_filled.png").c_str(), w1, h1, 0);
+    std::cout << "writing images ..." << std::endl;
+    struct U8Out { const char* name; const unsigned char* data; };
+    struct F32Out { const char* name; const float* data; };
+    const U8Out u8_outputs[] = {{"image_left.png", gray[0]}, {"image_right.png", gray[1]},
+                                {"image_mean_left.png", mean[0].data()},
+                                {"image_mean_right.png", mean[1].data()}};
+    // file names of the reference (its cost images are named after its default range)
+    const F32Out f32_outputs[] = {{"best_costl.png", best[0].data()},       {"best_costr.png", best[1].data()},
+                                  {"cost_lminus15.png", cost[0].data()},    {"cost_rminus15.png", cost[1].data()},
+                                  {"occlu_mapl.png", occlusion.data()},     {"disparity_mapl.png", dmap[0].data()},
+                                  {"disparity_mapr.png", dmap[1].data()},   {"occlu_mapl_filled.png", filled.data()}};
+    for (const U8Out& o : u8_outputs) smx_png_write((outdir + "/" + o.name).c_str(), w, h, 1, o.data);
+    for (const F32Out& o : f32_outputs) {
+        const std::vector<unsigned char> img = normalise_like_reference(o.data, (size_t)n);
+        smx_png_write((outdir + "/" + o.name).c_str(), w, h, 1, img.data());
+    }
 
     std::cout << "duration: " << duration << std::endl;
-    cout << "Free the memory ..." << endl;
-    free(occlusion); free(occlusion_filled); free(I_l); free(I_r); free(data1); free(data2);
-    free(mean1); free(mean2); free(costl); free(costr); free(dmapl); free(dmapr);
-    free(best_costr); free(best_costl); free(dmaprChar); free(dmaplChar);
+    std::cout << "Free the memory ..." << std::endl;
+    for (int v = 0; v < 2; ++v) { std::free(gray[v]); std::free(in.rgb[v]); }
     return 0;
 }

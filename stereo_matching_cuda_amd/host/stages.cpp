@@ -22,29 +22,24 @@ smx_host_config& smx_config() {
     return c;
 }
 
-// helpers.cu:3-25
-bool check_errors(float* resCPU, float* resGPU, int len) {
-    bool res = true;
-    for (int i = 0; i < len; i++) {
-        if (resCPU[i] != resGPU[i]) {
-            res = false;
-            cout << "error at element: " << i << " ResultGPU = " << resGPU[i]
-                 << " and ResultCPU= " << resCPU[i] << endl;
-        }
+// helpers.cu:3-25 -- exact-equality compare that reports every mismatching element
+namespace {
+template <class T>
+bool report_mismatches(const T* expected, const T* got, int len) {
+    int mismatches = 0;
+    for (int k = 0; k < len; ++k) {
+        if (expected[k] == got[k]) continue;
+        ++mismatches;
+        cout << "error at element: " << k << " ResultGPU = " << +got[k] << " and ResultCPU= " << +expected[k]
+             << endl;
     }
-    return res;
+    return mismatches == 0;
 }
+}  // namespace
 
+bool check_errors(float* resCPU, float* resGPU, int len) { return report_mismatches(resCPU, resGPU, len); }
 bool check_errors(unsigned char* resCPU, unsigned char* resGPU, int len) {
-    bool res = true;
-    for (int i = 0; i < len; i++) {
-        if (resCPU[i] != resGPU[i]) {
-            res = false;
-            cout << "error at element: " << i << " ResultGPU = " << (int)resGPU[i]
-                 << " and ResultCPU= " << (int)resCPU[i] << endl;
-        }
-    }
-    return res;
+    return report_mismatches(resCPU, resGPU, len);
 }
 
 // rgb_to_grayscale.cu:25-73
