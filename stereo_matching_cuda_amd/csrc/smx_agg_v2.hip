@@ -34,6 +34,14 @@
 #ifndef SMX_EXP
 #define SMX_EXP 0   // timing experiments (tools/exp_build.sh); 0 = product build
 #endif
+#ifndef SMX_AB_LOAD_AUX
+#define SMX_AB_LOAD_AUX 2
+#endif
+#if SMX_EXP == 4     // timing experiment: no workgroup barriers in the walker
+#define WALK_SYNC() ((void)0)
+#else
+#define WALK_SYNC() __syncthreads()
+#endif
 
 #include "smx_common.h"
 #include "smx_launch.h"
@@ -62,10 +70,6 @@ enum Mode { GUID = 0, S1 = 1, S2 = 2 };
 // truncated cost terms like the reference's out-of-range branch (costVolume.cu:184).
 typedef _Float16 fg_t __attribute__((ext_vector_type(2)));
 
-// Addressing idiom of this file: every global access is  uniform_pointer + 32-bit lane BYTE offset
-// so the compiler keeps the pointer in SGPRs (global_load ... v_off, s[base:base+1]) instead of
-// building a 64-bit VGPR address per access (two VGPRs per outstanding load).  The offset must be
-// a 32-bit value that is zero-extended as is -- `ptr[lane]` (zext then shift) does not match.
 // Band-blocked transposed plane layout ("[band][x][64 rows]"): element (x, y) of a plane that is
 // Wp columns wide lives at  ((y >> 6) * Wp + x) * 64 + (y & 63).  A wave (LANE = ROW, 64 rows of one
 // band) touches 256 contiguous bytes per column and consecutive columns are adjacent, so a band
@@ -74,15 +78,6 @@ typedef _Float16 fg_t __attribute__((ext_vector_type(2)));
 __host__ __device__ __forceinline__ size_t bcol(int x) { return (size_t)x * 64; }
 __host__ __device__ __forceinline__ unsigned blane(int y, int Wp) {
     return ((unsigned)(y >> 6) * (unsigned)Wp) * 64u + (unsigned)(y & 63);
-}
-
-template <class T>
-__device__ __forceinline__ T ldl(const T* ubase, unsigned boff) {
-    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(ubase) + boff);
-}
-template <class T>
-__device__ __forceinline__ void stl(T* ubase, unsigned boff, T v) {
-    *reinterpret_cast<T*>(reinterpret_cast<char*>(ubase) + boff) = v;
 }
 
 // Buffer-descriptor accesses for the walker: 128-bit descriptor in SGPRs (built from kernel
@@ -102,16 +97,26 @@ __device__ __forceinline__ uint32_t bld(rsrc_t r, unsigned voff, unsigned soff) 
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0);
 #endif
 }
+// streamed-once inputs (a, b planes): non-temporal so they do not displace the re-read image planes
+__device__ __forceinline__ uint32_t bld_nt(rsrc_t r, unsigned voff, unsigned soff) {
+#if SMX_EXP == 3
+    return voff + soff;
+#else
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, SMX_AB_LOAD_AUX);
+#endif
+}
 __device__ __forceinline__ float bldf(rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
-// streamed outputs (a, b, q): sc1 stores do not keep the line in the XCD's L2, which the small image
-// / guidance planes re-read by every slice need more (MI355X_MICROARCH.md, "stores of each flavour")
+// Cache policy of the streamed outputs, measured on KITTI shape (ms per pair, sc1 / plain / nt):
+// a,b stores of stage 1: walk<S1> 0.76 / 0.70 / 0.85, the following carry<S2> 0.41 / 0.38 / 0.32;
+// q stores of stage 2: walk<S2> 0.80 / 0.77 / 0.75.  Plain for a,b and nt for q is the best total.
+template <int AUX>
 __device__ __forceinline__ void bstf(rsrc_t r, unsigned voff, unsigned soff, float v) {
 #if SMX_EXP == 1   // timing experiment: no output stores (keep the value alive)
     asm volatile("" ::"v"(v));
 #else
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, 16);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff, (int)soff, AUX);
 #endif
 }
 
@@ -215,8 +220,8 @@ struct Source {
                 r.a[t] = bld(img, yfg, fg1o + (unsigned)(c + 1) * 256u);
                 r.b[t] = bld(img, yfg, fg2o + (unsigned)(xx + 1) * 256u);
             } else {
-                r.a[t] = bld(ra, ypl, (unsigned)c * 256u);
-                r.b[t] = bld(rb, ypl, (unsigned)c * 256u);
+                r.a[t] = bld_nt(ra, ypl, (unsigned)c * 256u);
+                r.b[t] = bld_nt(rb, ypl, (unsigned)c * 256u);
             }
         }
     }
@@ -363,8 +368,8 @@ __device__ __forceinline__ void stage_out(const Args& a, const Planes& P, float 
         float mm = m0 * m0;          // pixelMultOnGPU(mean, mean) guidedFilter.cu:112
         float var = m1 - mm;         // pixelSousOnGPU :121
         float c = (float)(1.0f / ((double)var + a.eps));   // :350
-        bstf(P.dstA, yb, cob, m0);
-        bstf(P.dstB, yb, cob, c);
+        bstf<0>(P.dstA, yb, cob, m0);
+        bstf<0>(P.dstB, yb, cob, c);
         if (a.mean_u8) {             // flToChOnGPU :451-458
             int ci8 = (int)m0;
             a.mean_u8[(size_t)yo * a.w + xo] = (ci8 > 255) ? 255 : (uint8_t)ci8;
@@ -376,11 +381,11 @@ __device__ __forceinline__ void stage_out(const Args& a, const Planes& P, float 
         float ak = 1.0f * (m1 - mm) * c;
         float mb2 = 1.0f * mI * ak;
         float bk = 1.0f * m0 - mb2;
-        bstf(P.dstA, yb, cob, ak);
-        bstf(P.dstB, yb, cob, bk);
+        bstf<0>(P.dstA, yb, cob, ak);
+        bstf<0>(P.dstB, yb, cob, bk);
     } else {
         float tq = m0 * ga;          // compute_q guidedFilter.cu:363-369
-        bstf(P.dstA, yb, cob, tq + m1);
+        bstf<2>(P.dstA, yb, cob, tq + m1);
     }
 }
 
@@ -409,7 +414,7 @@ __device__ __forceinline__ void raw_load(const Planes& P, int w, int d, unsigned
         for (int t = 0; t < SUBW; ++t) {
             if (MODE == GUID) r.u[0][t] = bld(P.img, yfg, o1 + t * 256u);
             if (MODE == S1) { r.u[0][t] = bld(P.img, yfg, o1 + t * 256u); r.u[1][t] = bld(P.img, yfg, o2 + t * 256u); }
-            if (MODE == S2) { r.u[0][t] = bld(P.srcA, ypl, oa + t * 256u); r.u[1][t] = bld(P.srcB, ypl, oa + t * 256u); }
+            if (MODE == S2) { r.u[0][t] = bld_nt(P.srcA, ypl, oa + t * 256u); r.u[1][t] = bld_nt(P.srcB, ypl, oa + t * 256u); }
         }
         return;
     }
@@ -435,8 +440,8 @@ __device__ __forceinline__ void raw_load(const Planes& P, int w, int d, unsigned
         for (int t = 0; t < SUBW; ++t) {
             int c = c0 + t;
             c = c < 0 ? 0 : (c >= w ? w - 1 : c);
-            r.u[0][t] = bld(P.srcA, ypl, (unsigned)c * 256u);
-            r.u[1][t] = bld(P.srcB, ypl, (unsigned)c * 256u);
+            r.u[0][t] = bld_nt(P.srcA, ypl, (unsigned)c * 256u);
+            r.u[1][t] = bld_nt(P.srcB, ypl, (unsigned)c * 256u);
         }
     }
 }
@@ -589,9 +594,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
                 }
             }
         }
-        __syncthreads();
+        WALK_SYNC();
         // ---------------- phase C: LANE = COLUMN, R -> S in place ------------------------------
-        if (ci < 2) {
+        if (ci < 2 && SMX_EXP != 5) {
             // 64 dependent adds per column in batches of 8 rows.  y0 and RR are multiples of 8, so a
             // batch never straddles the ring wrap: one base address per batch, immediate offsets for
             // its rows.  Where registers allow (not in S1, which would spill) two batches ping-pong:
@@ -649,7 +654,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
             if (fastR) raw_load<MODE, true>(P, w, dsl, blane(y, w + 2) * 4u, blane(y, w) * 4u, cbeg, raw);
             else raw_load<MODE, false>(P, w, dsl, blane(y, w + 2) * 4u, blane(y, w) * 4u, cbeg, raw);
         }
-        __syncthreads();
+        WALK_SYNC();
         // ---------------- phase B: LANE = ROW, box means + stage arithmetic --------------------
 #if SMX_EXP == 2   // timing experiment: no phase B
         if (gA[0] == 12345.0f)
@@ -759,7 +764,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void k_v2_walk(Launch L) {
                 }
             }
         }
-        __syncthreads();
+        WALK_SYNC();
     }
 }
 
@@ -786,7 +791,7 @@ __global__ __launch_bounds__(64) void k_v2_wta(WtaArgs wa, int w, int h, int hp,
     for (; z + 8 <= count; z += 8) {
         float v[8];
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = q[(size_t)(z + t) * plane];
+        for (int t = 0; t < 8; ++t) v[t] = __builtin_nontemporal_load(&q[(size_t)(z + t) * plane]);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             uint64_t kk = pack_key(v[t], (uint32_t)(slice0 + z + t));
@@ -794,7 +799,7 @@ __global__ __launch_bounds__(64) void k_v2_wta(WtaArgs wa, int w, int h, int hp,
         }
     }
     for (; z < count; ++z) {
-        uint64_t kk = pack_key(q[(size_t)z * plane], (uint32_t)(slice0 + z));
+        uint64_t kk = pack_key(__builtin_nontemporal_load(&q[(size_t)z * plane]), (uint32_t)(slice0 + z));
         key = kk < key ? kk : key;
     }
     keys[id] = key;
