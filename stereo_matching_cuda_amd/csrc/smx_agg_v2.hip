@@ -1,24 +1,27 @@
 // smx_agg_v2.hip -- fused guided-filter aggregation for gfx950 ("carry prepass + strip walker").
 //
-// Data flow per view (reference: guidedFilter.cu:58-238; cost: costVolume.cu:163-190):
+// Data flow per call (reference: guidedFilter.cu:58-238; cost: costVolume.cu:163-190); every launch
+// covers both views of the pair (blockIdx.z / work-item order):
 //
-//   prep      u8 images -> transposed f32 planes F_T[x][y], G_T[x][y] (value, x-gradient) with one
-//             sentinel column on each side (out-of-range disparities read 1e9 -> both truncated
-//             terms saturate -> exactly the reference's border constant).
+//   prep      u8 images -> one plane of half2 (value, x-gradient) per image, transposed and band-
+//             blocked ([band][x][64 rows]), with one sentinel column (60000) on each side: out-of-
+//             range disparities saturate both truncated terms -> exactly the reference's border
+//             constant.
+//   events    segment start columns sorted ascending (8 sub-strips per strip interleave).
 //   carry<M>  one wave per (slice, 64-row band), LANE = ROW: walks the full row left->right with the
 //             reference's sequential f32 adds and stores the running row sums at every sub-strip
-//             start ("carries").  No LDS, output is ~3 % of a plane.
-//   walk<M>   one 256-thread workgroup per (slice, strip of TW columns), walking 64-row bands top->
-//             bottom entirely in LDS:
-//               phase R  LANE = ROW   : each wave continues the row scan of one SUBW-column sub-strip
-//                                       from its carry, writing R into the LDS ring (strided, odd
-//                                       pitch -> conflict-free)
+//             start ("carries").  No LDS, output is ~6 % of a plane.
+//   walk<M>   one 512-thread workgroup per (slice, strip of TW = 104 columns), walking 64-row bands
+//             top->bottom in a 96-row LDS ring:
+//               phase R  LANE = ROW   : each of the 8 waves continues the row scan of one 13-column
+//                                       sub-strip from its carry, writing R into the ring (strided,
+//                                       odd pitch -> conflict-free)
 //               phase C  LANE = COLUMN: sequential column scan down the band, S kept in a register
 //                                       per column across bands, R -> S in place in the ring
-//               phase B  LANE = ROW   : box means from the ring (4 taps, reference order, IEEE
-//                                       division) + the per-pixel arithmetic of the stage; outputs
-//                                       are written transposed ([x][y]) so the next stage's LANE=ROW
-//                                       readers are coalesced
+//               phase B  LANE = ROW   : box means from the ring (4 taps, reference order, division
+//                                       bit-identical to IEEE) + the per-pixel arithmetic of the
+//                                       stage; outputs are written in the band-blocked transposed
+//                                       layout so the next stage's LANE=ROW readers are coalesced
 //             The addition order of every prefix sum is exactly the reference's (integral.cu:82-86,
 //             124-128); strips overlap by 2R+1 recomputed columns instead of exchanging halos.
 //   modes     GUID: (I, I*I)      -> mean_I, 1/(var+eps)      (guidedFilter.cu:58-123)
@@ -28,14 +31,15 @@
 //   wta       one lane per pixel over the q planes of the chunk, packed-key min
 //             (dispSelectOnGPU guidedFilter.cu:403-411).
 //
-// Must be compiled with -ffp-contract=off.
+// Must be compiled with -ffp-contract=off.  SMX_EXP selects timing-experiment variants whose
+// results are wrong by design (tools/exp_build.sh); the product build is SMX_EXP == 0.
 #include <string.h>
 
 #ifndef SMX_EXP
 #define SMX_EXP 0   // timing experiments (tools/exp_build.sh); 0 = product build
 #endif
 #ifndef SMX_AB_LOAD_AUX
-#define SMX_AB_LOAD_AUX 2
+#define SMX_AB_LOAD_AUX 2   // nt: a,b planes are read once per kernel (carry<S2> -23 %, walk<S2> -7 % vs default)
 #endif
 #if SMX_EXP == 4     // timing experiment: no workgroup barriers in the walker
 #define WALK_SYNC() ((void)0)
