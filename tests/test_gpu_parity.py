@@ -270,6 +270,35 @@ def test_fused_path_parameter_variations(orc, radius, alpha, thc, thg, eps, dmin
         _eq(r[k], want[k], k)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fused_path_fuzz(orc, seed):
+    """Seeded random shapes, disparity ranges and parameters through the fused path vs the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    w = int(rng.integers(2, 420))
+    h = int(rng.integers(1, 260))
+    D = int(rng.integers(1, 70))
+    p = smx.default_params()
+    p.radius = int(rng.integers(0, 10))
+    p.alpha = float(rng.choice([0.9, 0.5, 0.1]))
+    p.th_color = int(rng.integers(1, 30))
+    p.th_grad = int(rng.integers(1, 8))
+    p.eps = float(rng.choice([6.5025, 100.0, 0.5]))
+    p.d_lr = int(rng.integers(0, 3))
+    dminl = int(-rng.integers(0, 2 * D + 3))
+    dminr = int(rng.integers(-3, D + 3))
+    shift = int(rng.integers(0, max(1, min(D, w // 3))))
+    base = rng.integers(0, 256, size=(h, w + D + 8), dtype=np.uint8)
+    if seed % 3 == 0:                         # flat regions: zero costs, exact ties, tiny sums
+        base = (base // 64 * 64).astype(np.uint8)
+    Il = np.ascontiguousarray(base[:, :w])
+    Ir = np.ascontiguousarray(base[:, shift:shift + w])
+    po = orc.Params.from_buffer_copy(bytes(p))
+    want = orc.stereo_pair(Il, Ir, D, dminl=dminl, dminr=dminr, want_agg=True, params=po)
+    r = _device_pair(Il, Ir, D, dminl=dminl, dminr=dminr, want_agg=True, params=p)
+    for k in KEYS + ("aggl", "aggr"):
+        _eq(r[k], want[k], f"seed {seed} w={w} h={h} D={D} R={p.radius} {k}")
+
+
 def test_radius_above_nine_uses_the_multi_kernel_path(orc):
     w, h, D = 90, 70, 5
     rng = np.random.default_rng(77)
