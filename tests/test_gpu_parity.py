@@ -385,9 +385,9 @@ def test_pair_kitti_shape_synthetic(orc):
     """BASELINE config 4 shape (1242x375, D=192), seeded synthetic pair, vs the oracle."""
     w, h, D = synth.SHAPES["kitti"]
     Il, Ir = synth.gen_pair(w, h, D, synth.SEEDS["kitti"])
-    want = orc.stereo_pair(Il, Ir, D)
-    r = _device_pair(Il, Ir, D)
-    for k in KEYS:
+    want = orc.stereo_pair(Il, Ir, D, want_agg=True)
+    r = _device_pair(Il, Ir, D, want_agg=True)
+    for k in KEYS + ("aggl", "aggr"):      # the aggregated volumes too: 2 x 89.4 M cells, bit for bit
         _eq(r[k], want[k], k)
 
 
