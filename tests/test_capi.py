@@ -101,3 +101,21 @@ def test_write_mat_matches_reference_normaliser(orc):
     assert np.array_equal(smx.write_mat(m), orc.write_mat_u8(m))
     m = np.arange(12, dtype=np.float32).reshape(3, 4)   # strictly increasing: min never updated
     assert np.array_equal(smx.write_mat(m), orc.write_mat_u8(m))
+
+
+def test_header_is_plain_c_and_links(lib, tmp_path):
+    """include/smx.h must be consumable from C (the boundary is a C-ABI, not a C++ API)."""
+    import subprocess
+    src = tmp_path / "c_abi.c"
+    src.write_text('#include "smx.h"\n#include <stdio.h>\n'
+                   'int main(void) { smx_params p; smx_default_params(&p);\n'
+                   '  printf("%s %d %g\\n", smx_version(), p.radius, p.eps);\n'
+                   '  return smx_device_count() < 0; }\n')
+    exe = tmp_path / "c_abi"
+    inc = os.path.dirname(_lib.HEADER_PATH)
+    libdir = os.path.dirname(_lib.SO_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc,
+                           str(src), "-o", str(exe), "-L", libdir, "-lsmx_hip",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0 and "9 6.5025" in out.stdout
