@@ -156,6 +156,13 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
                                uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
                                size_t workspace_bytes, void* stream);
 
+/* Synchronous health check of the last smx_dev_aggregate_wta[_pair] call that used d_workspace:
+ * copies the call's status word back (implicit stream synchronisation of the null stream; call it
+ * after synchronising the launch stream).  SMX_E_HIP if a workgroup of the fused kernel gave up
+ * waiting for its left neighbour (the spins are bounded, 2 s), in which case the results are
+ * invalid.  Not needed for correctness in normal operation. */
+int smx_dev_agg_status(const void* d_workspace);
+
 /* Aggregation implementation: 0 = auto (fused strip-walker kernels when the cost is built on the
  * fly and radius <= 9, else the multi-kernel path), 1 = force multi-kernel, 2 = force fused (error
  * if not applicable).  Process-wide; for tests and A/B timing.  smx_last_agg_path() reports which

@@ -14,7 +14,7 @@ static thread_local bool g_timing = false;
 static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static thread_local bool g_ev_valid = false;
 static thread_local int g_launches = 0;
-static int g_agg_path = 0;                 // 0 auto, 1 force v1 (multi-kernel), 2 force v2 (fused)
+static int g_agg_path = 0;                 // 0 auto, 1 multi-kernel, 2 fused (v3), 3 round-1 fused (v2, A/B only)
 static thread_local int g_last_path = 0;
 
 // smx_agg_v2.hip
@@ -25,6 +25,16 @@ int aggregate_v2(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                  const uint8_t* const* d_other, int w, int h, const int* dmin, int s_begin, int s_end,
                  uint64_t* const* d_keys, uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws,
                  size_t ws_bytes, hipStream_t st, int* launches);
+// smx_agg_v3.hip
+bool v3_supported(const smx_params* p);
+size_t v3_workspace_bytes(int w, int h, int nslices);
+int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
+                 const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
+                 const int* dmin, int s_begin, int s_end, uint64_t* const* d_keys,
+                 uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
+                 hipStream_t st, int* launches);
+
+int v3_read_status(const void* d_ws, unsigned* out);
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -127,11 +137,13 @@ size_t smx_agg_workspace_bytes(int w, int h, int nslices) {
     // v1 path: guidance im, mean_im, cinv, S_im, S_sq ; per slice in flight: cost, T0, T1, A, B
     const size_t v1 = plane_bytes(w, h) * (5 + 5 * (size_t)nslices) + WS_ALIGN;
     const size_t v2b = v2_workspace_bytes(w, h, -1, nslices);
-    return v1 > v2b ? v1 : v2b;
+    const size_t v3b = v3_workspace_bytes(w, h, nslices);
+    const size_t m = v1 > v2b ? v1 : v2b;
+    return m > v3b ? m : v3b;
 }
 
 int smx_set_agg_path(int path) {
-    if (path < 0 || path > 2) return fail(SMX_E_ARG, "smx_set_agg_path: path must be 0, 1 or 2");
+    if (path < 0 || path > 3) return fail(SMX_E_ARG, "smx_set_agg_path: path must be 0 .. 3");
     g_agg_path = path;
     return SMX_OK;
 }
@@ -140,6 +152,17 @@ int smx_last_agg_path(void) { return g_last_path; }
 
 int smx_set_agg_pipeline(int subchunks) {
     v2_set_pipeline(subchunks);
+    return SMX_OK;
+}
+
+int smx_dev_agg_status(const void* d_workspace) {
+    SMX_ARG(d_workspace);
+    unsigned st = 0;
+    int rc = v3_read_status(d_workspace, &st);
+    if (rc) return rc;
+    if (st != 0)
+        return fail(SMX_E_HIP, "fused aggregation: hand-off wait of work item %u timed out (results invalid)",
+                    st - 1);
     return SMX_OK;
 }
 
@@ -178,22 +201,29 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
     SMX_ARG(d_cost || d_other);
     SMX_ARG(w >= 2 && h >= 1 && s_begin >= 0 && s_end >= s_begin && p->radius >= 0);
     hipStream_t st = (hipStream_t)stream;
-    // fused path: cost built on the fly, radius <= 9 (smx_agg_v2.hip)
+    // fused path (smx_agg_v3.hip): radius <= 9; cost built on the fly or read from d_cost
+    const bool can_v3 = v3_supported(p);
     const bool can_v2 = !d_cost && d_other && v2_supported(p);
-    if (g_agg_path == 2 && !can_v2)
-        return fail(SMX_E_ARG, "smx_dev_aggregate_wta: fused path forced but not applicable "
-                               "(needs d_cost == NULL, d_other != NULL, radius <= 9)");
-    if (can_v2 && g_agg_path != 1) {
+    if (g_agg_path == 2 && !can_v3)
+        return fail(SMX_E_ARG, "smx_dev_aggregate_wta: fused path forced but radius > 9");
+    if (g_agg_path == 3 && !can_v2)
+        return fail(SMX_E_ARG, "smx_dev_aggregate_wta: round-1 fused path forced but not applicable");
+    if ((can_v3 && (g_agg_path == 0 || g_agg_path == 2)) || g_agg_path == 3) {
         g_launches = 0;
         if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
-        int rc2 = aggregate_v2(p, 1, &d_guide, &d_other, w, h, &dmin, s_begin, s_end, &d_keys,
+        int rc2;
+        if (g_agg_path == 3)
+            rc2 = aggregate_v2(p, 1, &d_guide, &d_other, w, h, &dmin, s_begin, s_end, &d_keys,
+                               &d_mean_u8, &d_agg, d_workspace, workspace_bytes, st, &g_launches);
+        else
+            rc2 = aggregate_v3(p, 1, &d_guide, &d_other, &d_cost, w, h, &dmin, s_begin, s_end, &d_keys,
                                &d_mean_u8, &d_agg, d_workspace, workspace_bytes, st, &g_launches);
         if (rc2) return rc2;
         if (g_timing) {
             SMX_HIP(hipEventRecord(g_ev1, st));
             g_ev_valid = true;
         }
-        g_last_path = 2;
+        g_last_path = g_agg_path == 3 ? 3 : 2;
         return SMX_OK;
     }
     g_last_path = 1;
@@ -265,7 +295,7 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)w * h;
     const int64_t vol = n * (s_end - s_begin);
-    if (v2_supported(p) && g_agg_path != 1) {
+    if (v3_supported(p) && g_agg_path != 1) {
         const uint8_t* guide[2] = {d_left, d_right};
         const uint8_t* other[2] = {d_right, d_left};
         const int dmin[2] = {dminl, dminr};
@@ -274,7 +304,13 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
         float* agg[2] = {d_agg, d_agg ? d_agg + vol : nullptr};
         g_launches = 0;
         if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
-        int rc2 = aggregate_v2(p, 2, guide, other, w, h, dmin, s_begin, s_end, keys,
+        int rc2;
+        if (g_agg_path == 3)
+            rc2 = aggregate_v2(p, 2, guide, other, w, h, dmin, s_begin, s_end, keys,
+                               d_mean_u8 ? mean : nullptr, d_agg ? agg : nullptr, d_workspace,
+                               workspace_bytes, st, &g_launches);
+        else
+            rc2 = aggregate_v3(p, 2, guide, other, nullptr, w, h, dmin, s_begin, s_end, keys,
                                d_mean_u8 ? mean : nullptr, d_agg ? agg : nullptr, d_workspace,
                                workspace_bytes, st, &g_launches);
         if (rc2) return rc2;
@@ -282,7 +318,7 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
             SMX_HIP(hipEventRecord(g_ev1, st));
             g_ev_valid = true;
         }
-        g_last_path = 2;
+        g_last_path = g_agg_path == 3 ? 3 : 2;
         return SMX_OK;
     }
     if (g_agg_path == 2)

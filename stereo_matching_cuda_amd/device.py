@@ -114,9 +114,14 @@ class PairPipeline:
         self.keys.bitwise_xor_(_I64_MIN)
         return self.keys
 
+    def check_status(self):
+        """Raise if a workgroup of the fused aggregation gave up waiting for a neighbour."""
+        torch.cuda.synchronize(self.device)
+        _lib.check(self.lib.smx_dev_agg_status(_dp(self.ws)))
+
     def results(self):
         """Host copies (numpy) named like the oracle's dict."""
-        torch.cuda.synchronize(self.device)
+        self.check_status()
         c = lambda t: t.detach().cpu().numpy()
         r = {"bestl": c(self.best[0]), "bestr": c(self.best[1]), "dmapl": c(self.dmap[0]),
              "dmapr": c(self.dmap[1]), "meanl": c(self.mean[0]), "meanr": c(self.mean[1]),
