@@ -46,17 +46,15 @@ constexpr int HWMAX = 2 * RMAX + 1;     // halo / overlap columns
 constexpr int TWMAX = OW + HWMAX;       // ring columns in use (83 at R = 9)
 constexpr int PITCH = 86;               // float2 per ring row: even (16-B aligned column pairs) and
                                         // PITCH/2 odd (LANE = ROW 16-B accesses hit distinct banks)
-constexpr int BH = 32;                  // band height
-constexpr int RR = 3 * BH;              // ring rows
 constexpr int NT = 1024;
 constexpr int NWAVE = NT / 64;
 constexpr int W_R = 0;                  // row-scan wave
-constexpr int W_C = 1;                  // column-scan wave
-constexpr int W_B0 = 2;                 // first box / eval wave
-constexpr int NWB = NWAVE - W_B0;       // 14
-constexpr int NTB = NWB * 64;           // 896
-constexpr int W_POLL = NWAVE - 1;       // wave whose lane 0 polls the left neighbour's flag
-static_assert(BH * HWMAX <= NTB, "halo columns of a band are loaded in one pass");
+constexpr int W_C = 1;                  // column-scan wave (ring columns 0 .. 63)
+constexpr int W_IO = 2;                 // hand-off I/O wave (+ column scan of ring columns 64 ..)
+constexpr int W_B0 = 3;                 // first box / eval wave
+constexpr int NWB = NWAVE - W_B0;       // 13
+constexpr int BH = 2 * NWB;             // band height: every box wave owns two rows of a band
+constexpr int RR = 3 * BH;              // ring rows
 static_assert(RR >= 2 * BH + 2 * RMAX + 2, "ring too small for the two-step pipeline");
 
 enum Mode { GUID = 0, AGG = 1 };
@@ -81,8 +79,7 @@ struct View {
 struct Args {
     View v[2];
     int w, h, R, K, NB, nslices, nsv, nitems;
-    f2* carry;            // [parity][stage][sv][h]
-    f2* halo;             // [parity][sv][h][HWMAX]
+    f2* hand;             // hand-off records [parity][sv][band] (see REC_F2)
     unsigned* flags;      // [sv][K]   finished-band counters (zeroed before every launch)
     unsigned* ticket;     // work-item counter            (zeroed before every launch)
     unsigned* status;     // != 0: a flag wait timed out (results invalid)
@@ -203,22 +200,69 @@ __global__ void k_v3_prep(PrepArgs pa, int w, int h) {
 // ---------------------------------------------------------------------------------------------
 // the walker
 // ---------------------------------------------------------------------------------------------
+// Diagnostic build only (-DSMX_V3_STAMPS, tools/v3_stamps.sh): every wave of one work item records
+// the shader clock around its two barriers per band; the product build contains no stamp.
+#ifdef SMX_V3_STAMPS
+constexpr int STAMP_SLOTS = 4 * 96;
+__device__ unsigned long long g_stamps[NWAVE * STAMP_SLOTS];
+#define V3_STAMP(n)                                                                          \
+    do {                                                                                     \
+        if (item == SMX_V3_STAMPS && lane == 0 && (i + 2) * 4 + (n) < STAMP_SLOTS)            \
+            g_stamps[wave * STAMP_SLOTS + (i + 2) * 4 + (n)] = __builtin_amdgcn_s_memtime();  \
+    } while (0)
+#else
+#define V3_STAMP(n) ((void)0)
+#endif
+// Workgroup barrier that orders LDS only: __syncthreads() would also wait for every outstanding
+// global load and store (vmcnt(0)), which is exactly the latency the cross-step prefetches hide.
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 ld16_sc1(rsrc_t r, unsigned byteoff) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byteoff, 0, AUX_SC1));
+}
+__device__ __forceinline__ void st16_sc1(rsrc_t r, unsigned byteoff, f4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, (int)byteoff, 0, AUX_SC1);
+}
+__device__ __forceinline__ f2 lo2(f4 v) { f2 r = {v.x, v.y}; return r; }
+__device__ __forceinline__ f2 hi2(f4 v) { f2 r = {v.z, v.w}; return r; }
+
+// Hand-off record of one band (per parity and slice-view), written and read in 16-byte units:
+//   [0, BH)            stage-1 row carries (float2 per row of the band)
+//   [BH, 2 BH)         stage-2 row carries
+//   [2 BH, 2 BH + BH*HP) last 2R+1 columns of a, b, HP = 20 float2 per row
+constexpr int HP = HWMAX + 1;
+constexpr int REC_F2 = 2 * BH + BH * HP;          // float2 per band record
+constexpr int NHU = (BH * HP / 2 + 63) / 64;      // 16-byte halo units per lane of the I/O wave
+static_assert(BH % 2 == 0 && HP % 2 == 0 && (REC_F2 % 2) == 0, "16-byte hand-off units");
+static_assert(BH == 2 * NWB, "every box wave owns two rows of a band");
+
 template <int MODE, int SRC>
 __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
     __shared__ __attribute__((aligned(16))) f2 ring1[RR * PITCH];
     __shared__ __attribute__((aligned(16))) f2 ring2[MODE == AGG ? RR * PITCH : 2];
+    // hand-off staging (all global hand-off traffic goes through the I/O wave, one step delayed):
+    __shared__ __attribute__((aligned(16))) f2 cin[2][BH];    // row carries in : stage -> rows of the band
+    __shared__ __attribute__((aligned(16))) f2 cout[2][BH];   // row carries out
+    __shared__ __attribute__((aligned(16))) f2 hout[BH * HP]; // last 2R+1 columns of a, b of the band (AGG)
+    __shared__ float rcp_s[HWMAX * HWMAX + 1];                // RN(1/area)
     __shared__ int s_item;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w = A.w, h = A.h, R = A.R, K = A.K, NB = A.NB, nsv = A.nsv;
     const int HW = 2 * R + 1, TW = OW + HW;
-    const float invTW = 1.0f / (float)TW, invHW = 1.0f / (float)HW;
     const CostConst cc = A.cc;
-    const bool is_b = wave >= W_B0;
     const int wb = wave - W_B0;                 // box-wave index
-    const int tb = wb * 64 + lane;              // thread index among the box waves
     const f2 ident = {-0.0f, -0.0f};            // exact additive identity: v + (-0) == v
+    constexpr unsigned FLAG_DONE = 0x7fffffffu;
+    if (tid <= HWMAX * HWMAX) rcp_s[tid] = kRcp.v[tid];
+    // the three scan waves are latency chains on the critical path of every step: let them win the
+    // issue arbitration against the box waves that share their SIMDs
+    if (wave < W_B0) __builtin_amdgcn_s_setprio(3);
 
     for (;;) {
         if (tid == 0) s_item = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED,
@@ -234,167 +278,76 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
         const int xs = k * OW;
         const int cs1 = xs - R - 1;             // image column of ring-1 column 0
         const int cs2 = xs - HW;                // image column of ring-2 column 0
-        const int jlo1 = max(0, -cs1), jhi1 = min(TW, w - cs1);   // ring-1 columns inside the image
-        const int jlo2 = max(0, -cs2), jhi2 = min(TW, w - cs2);
         const bool pred = k > 0, succ = k + 1 < K;
-        const int d = V.d0 + slice;
-        unsigned* const myflag = A.flags + (size_t)sv * K + k;
-        bool pred_done = !pred;                 // lane 0 of W_POLL: no more polling needed
-        // hand-off scratch of this item (in: written by strip k-1, out: read by strip k+1)
-        const size_t hrow = (size_t)h;
-        const int pin = (k - 1) & 1, pout = k & 1;
-        const rsrc_t c1_in = mk_rsrc(A.carry + ((size_t)(pin * 2 + 0) * nsv + sv) * hrow, hrow * 8);
-        const rsrc_t c2_in = mk_rsrc(A.carry + ((size_t)(pin * 2 + 1) * nsv + sv) * hrow, hrow * 8);
-        const rsrc_t c1_out = mk_rsrc(A.carry + ((size_t)(pout * 2 + 0) * nsv + sv) * hrow, hrow * 8);
-        const rsrc_t c2_out = mk_rsrc(A.carry + ((size_t)(pout * 2 + 1) * nsv + sv) * hrow, hrow * 8);
-        const rsrc_t h_in = mk_rsrc(A.halo + ((size_t)pin * nsv + sv) * hrow * HWMAX, hrow * HWMAX * 8);
-        const rsrc_t h_out = mk_rsrc(A.halo + ((size_t)pout * nsv + sv) * hrow * HWMAX, hrow * HWMAX * 8);
-        const fg_t* __restrict__ FG1 = V.FG1;
-        const fg_t* __restrict__ FG2 = V.FG2;
-        const size_t fgw = (size_t)w + 2;
 
-        // running column sums of the column-scan wave: lane = ring column (second: lane + 64)
-        f2 S1a = ident, S1b = ident, S2a = ident, S2b = ident;
+        // rows of band b in the three lagged row spaces (stage-1 rows, a/b rows, q rows)
+        auto rows1 = [&](int b, int& lo, int& hi) { lo = b * BH; hi = min(h, b * BH + BH); if (b < 0 || b >= NB) hi = lo; };
+        auto rows2 = [&](int b, int& lo, int& hi) { lo = max(0, b * BH - R); hi = min(h, b * BH + BH - R); if (b < 0) hi = lo; };
+        auto rows3 = [&](int b, int& lo, int& hi) { lo = max(0, b * BH - 2 * R); hi = min(h, b * BH + BH - 2 * R); if (b < 0) hi = lo; };
 
-        // ---- stage-1 inputs of band b -> ring 1 (box waves, LANE = flattened (row, column)) -----
-        constexpr int NE = (BH * TWMAX + NTB - 1) / NTB;   // cells per thread
-        auto e1_issue = [&](int b, uint32_t (&ua)[NE], uint32_t (&ub)[NE]) {
-            const int y0 = b * BH;
-            const int nrows = min(BH, h - y0);
+        // column scan of rows [lo, hi) for the ring column `col` of this lane (LANE = COLUMN); runs of
+        // consecutive ring rows, so the LDS addresses of a batch are one base + immediates
+        auto colscan = [&](f2* ring, int col, int lo, int hi, f2& S) {
+            int rr = lo % RR, n = hi - lo;
+            while (n > 0) {
+                const int run = min(n, RR - rr);
+                f2* p = ring + rr * PITCH + col;
+                int t0 = 0;
+                for (; t0 + 8 <= run; t0 += 8) {      // 8 rows of LDS reads in flight ahead of the adds
+                    f2 v[8];
 #pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const int t = tb + e * NTB;
-                const int r = (int)(((float)t + 0.5f) * invTW);
-                const int j = t - r * TW;
-                const int c = cs1 + j;
-                ua[e] = 0; ub[e] = 0;
-                if (r < nrows && c >= 0 && c < w) {
-                    const size_t row = (size_t)(y0 + r);
-                    ua[e] = __builtin_bit_cast(uint32_t, FG1[row * fgw + c + 1]);
-                    if (MODE == AGG && SRC == SRC_IMG) {
-                        int xx = c + d;
-                        xx = xx < -1 ? -1 : (xx > w ? w : xx);   // sentinel columns
-                        ub[e] = __builtin_bit_cast(uint32_t, FG2[row * fgw + xx + 1]);
+                    for (int t = 0; t < 8; ++t) v[t] = p[(t0 + t) * PITCH];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        S = v[t] + S;
+                        p[(t0 + t) * PITCH] = S;
                     }
-                    if (MODE == AGG && SRC == SRC_COST)
-                        ub[e] = __builtin_bit_cast(uint32_t, V.cost[((size_t)slice * h + row) * w + c]);
                 }
-            }
-        };
-        auto e1_finish = [&](int b, const uint32_t (&ua)[NE], const uint32_t (&ub)[NE]) {
-            const int y0 = b * BH;
-            const int nrows = min(BH, h - y0);
-#pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const int t = tb + e * NTB;
-                const int r = (int)(((float)t + 0.5f) * invTW);
-                const int j = t - r * TW;
-                const int c = cs1 + j;
-                if (r < nrows && c >= 0 && c < w) {
-                    const fg_t q1 = __builtin_bit_cast(fg_t, ua[e]);
-                    f2 v;
-                    if (MODE == GUID) {
-                        v.x = (float)q1.x;            // chToFlOnGPU guidedFilter.cu:442-449
-                        v.y = v.x * v.x;              // pixelMultOnGPU(d_im, d_im) :111
-                    } else if (SRC == SRC_IMG) {
-                        v = cost_pair(q1, __builtin_bit_cast(fg_t, ub[e]), cc);
-                    } else {
-                        v.x = __builtin_bit_cast(float, ub[e]);   // copyFromBigToLittleOnGPU :198
-                        v.y = (float)q1.x * v.x;                  // pixelMultOnGPU(d_im, d_p) :209
-                    }
-                    ring1[((y0 + r) % RR) * PITCH + j] = v;
+                for (; t0 < run; ++t0) {
+                    S = p[t0 * PITCH] + S;
+                    p[t0 * PITCH] = S;
                 }
+                n -= run;
+                rr = 0;
             }
         };
 
-        // ---- row scan of `n` rows starting at image row ylo (LANE = ROW) ----------------------
-        auto rowscan = [&](f2* ring, int ylo, int n, int jlo, int jhi, rsrc_t cin, rsrc_t cout) {
-            if (lane >= n || jhi <= jlo) return;
-            const int y = ylo + lane;
-            f2 acc = ident;
-            if (pred) acc = ld_sc1(cin, (unsigned)y * 8u);
-            f2* row = ring + (y % RR) * PITCH;
-            int j = jlo;
-            for (; j + 8 <= jhi; j += 8) {
-                f2 v[8];
+        if (wave == W_IO) {
+            // =====================================================================================
+            // I/O wave (+ column scan of the ring columns 64 .. TW-1).
+            // Global step index t: A(i) = 2i + 4, B(i) = 2i + 5 (i >= -2).
+            // Data another strip needs (row carries, halo columns) is produced into LDS at step t by
+            // the row-scan / box waves, stored to global (sc1, 16 B per lane) by this wave at the start
+            // of step t + 1 and published at step t + 2, after this wave's own s_waitcnt vmcnt(0):
+            // flag = t.  Inputs for step t are loaded at step t - 2 (needs the neighbour's flag >= t)
+            // and moved to LDS at step t - 1, so neither direction exposes memory latency to the scans.
+            // =====================================================================================
+            unsigned* const myflag = A.flags + (size_t)sv * K + k;
+            bool pred_done = !pred;
+            const size_t recs = (size_t)NB * REC_F2;      // float2 per (parity, slice-view)
+            const rsrc_t r_in = mk_rsrc(A.hand + ((size_t)((k - 1) & 1) * nsv + sv) * recs, recs * 8);
+            const rsrc_t r_out = mk_rsrc(A.hand + ((size_t)(k & 1) * nsv + sv) * recs, recs * 8);
+            const bool ccol = lane + 64 < TW;             // this lane scans ring column lane + 64
+            f2 S1 = ident, S2 = ident;
+            f4 hreg[NHU];
+            f4 c1reg = {0, 0, 0, 0}, c2reg = {0, 0, 0, 0};
+            int hlo = 0, hhi = 0;        // a/b rows of the halo values in hreg
+            // halo unit t = lane + 64 e  ->  row t / (HP/2), column pair t % (HP/2)
+            int hu_r[NHU], hu_c[NHU];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) v[t] = row[j + t];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    acc = v[t] + acc;
-                    row[j + t] = acc;
-                    if (j + t == OW - 1 && succ) st_sc1(cout, (unsigned)y * 8u, acc);
-                }
+            for (int e = 0; e < NHU; ++e) {
+                const int t = lane + 64 * e;
+                hu_r[e] = t / (HP / 2);
+                hu_c[e] = (t - hu_r[e] * (HP / 2)) * 2;
             }
-            for (; j < jhi; ++j) {
-                acc = row[j] + acc;
-                row[j] = acc;
-                if (j == OW - 1 && succ) st_sc1(cout, (unsigned)y * 8u, acc);
-            }
-        };
-
-        // ---- column scan of rows [ylo, yhi) (LANE = COLUMN, two columns per lane) ---------------
-        auto colscan = [&](f2* ring, int ylo, int yhi, f2& Sa, f2& Sb) {
-            const bool second = lane + 64 < TW;
-            for (int y = ylo; y < yhi; ++y) {
-                f2* row = ring + (y % RR) * PITCH;
-                f2 va = row[lane];
-                f2 vb = second ? row[lane + 64] : ident;
-                Sa = va + Sa;
-                Sb = vb + Sb;
-                row[lane] = Sa;
-                if (second) row[lane + 64] = Sb;
-            }
-        };
-
-        // ---- box mean of output (x, y) from a ring whose column 0 is image column cs -----------
-        // (computeBoxFilterOnGPU guidedFilter.cu:305-318: S11 - S10 - S01 + S00 in that order, then
-        //  a true division by the clipped window area)
-        auto box = [&](const f2* ring, int cs, int x, int y) -> f2 {
-            const int ymax = min(h - 1, y + R);
-            const int ymin = y - R - 1;
-            const bool hy = ymin >= 0;
-            const int ych = ymax - (hy ? ymin : -1);
-            const int xmax = min(w - 1, x + R);
-            const int xmn = x - R - 1;
-            const bool hx = xmn >= 0;
-            const int xcw = xmax - (hx ? xmn : -1);
-            int jmax = xmax - cs, jmin = xmn - cs;
-            jmax = min(max(jmax, 0), TW - 1);            // lanes outside the image: stay inside the ring
-            jmin = min(max(jmin, 0), TW - 1);
-            const f2* r1 = ring + (ymax % RR) * PITCH;
-            const f2* r0 = ring + ((hy ? ymin : 0) % RR) * PITCH;
-            const f2 s11 = r1[jmax], s10 = r1[jmin], s01 = r0[jmax], s00 = r0[jmin];
-            f2 val = s11;
-            f2 t = val - s10;
-            val = hx ? t : val;
-            t = val - s01;
-            val = hy ? t : val;
-            t = val + s00;
-            val = (hx && hy) ? t : val;
-            int ai = xcw * ych;
-            ai = min(max(ai, 1), HWMAX * HWMAX);
-            const float area = (float)ai;
-            return box_div(val, area, kRcp.v[ai]);
-        };
-
-        // ================= prologue: stage-1 inputs of band 0 ==================================
-        if (is_b) {
-            uint32_t ua[NE], ub[NE];
-            e1_issue(0, ua, ub);
-            e1_finish(0, ua, ub);
-        }
-
-        // ================= pipelined band loop =================================================
-        for (int i = -1; i <= NB; ++i) {
-            // left neighbour must have finished steps A(i), B(i): its flag >= i + 2
-            if (wave == W_POLL && lane == 0 && !pred_done) {
-                const unsigned need = (unsigned)(i + 2);
+            auto wait_pred = [&](int t) {
+                if (pred_done) return;
+                const unsigned need = (unsigned)t;
                 const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
                 for (;;) {
                     const unsigned f = flag_load(myflag - 1);
-                    if (f >= need) { pred_done = f >= (unsigned)(NB + 2); break; }
-                    __builtin_amdgcn_s_sleep(8);
+                    if (f >= need) { pred_done = f == FLAG_DONE; break; }
+                    __builtin_amdgcn_s_sleep(4);
                     // bounded spin: give up after 2 s (100 MHz counter) or as soon as any workgroup
                     // has given up; the call then reports SMX_E_HIP through smx_dev_agg_status
                     if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull || flag_load(A.status) != 0u) {
@@ -403,117 +356,385 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                         break;
                     }
                 }
-            }
-            __syncthreads();
-            if (tid == 0 && succ && i >= 0) flag_store(myflag, (unsigned)(i + 1));   // B(i-1) done
-            // -------------------------------- step A(i) -----------------------------------------
-            if (wave == W_R) {
-                const int b = i + 1;                       // row scan, stage 1
-                if (b < NB && b * BH < h) rowscan(ring1, b * BH, min(BH, h - b * BH), jlo1, jhi1, c1_in, c1_out);
+            };
+            for (int i = -2; i <= NB + 1; ++i) {
+                int lo, hi;
+                // ------------------------------ step A(i), t = 2i + 4 ---------------------------
+                // everything this wave issued to global memory was issued at the start of the
+                // previous step: the wait is (nearly) free
                 drain_vmem();
-            } else if (wave == W_C) {
-                if (MODE == AGG) {
-                    const int b = i - 1;                   // column scan, stage 2
-                    if (b >= 0) {
-                        if (b == 0) { S2a = ident; S2b = ident; }
-                        colscan(ring2, max(0, b * BH - R), min(h, b * BH + BH - R), S2a, S2b);
-                    }
-                }
-            } else {
-                const int b = i;                           // box means of stage 1
-                const int ylo = max(0, b * BH - R), yhi = min(h, b * BH + BH - R);
-                if (b >= 0 && ylo < yhi) {
-                    // halo columns of a, b from the strip to the left (issued first, used last)
-                    f2 hv = ident;
-                    int hy2 = 0, hj = 0;
-                    bool hact = false;
-                    if (MODE == AGG && pred) {
-                        hy2 = (int)(((float)tb + 0.5f) * invHW);
-                        hj = tb - hy2 * HW;
-                        hact = hy2 < yhi - ylo;
-                        hy2 += ylo;
-                        if (hact) hv = ld_sc1(h_in, ((unsigned)hy2 * HWMAX + (unsigned)hj) * 8u);
-                    }
-                    if (xs < w) {
-                        const int x = xs + lane;
-                        const bool xin = x < w;
-                        const int xc = xin ? x : w - 1;
-                        for (int y = ylo + wb; y < yhi; y += NWB) {
-                            float ga = 0.0f, gb = 0.0f;
-                            if (MODE == AGG) {
-                                ga = V.mean[(size_t)y * w + xc];
-                                gb = V.cinv[(size_t)y * w + xc];
-                            }
-                            const f2 m = box(ring1, cs1, xc, y);
-                            if (MODE == GUID) {
-                                float mm = m.x * m.x;          // pixelMultOnGPU(mean, mean) guidedFilter.cu:112
-                                float var = m.y - mm;          // pixelSousOnGPU :121
-                                float c = (float)(1.0f / ((double)var + A.eps));   // :350
-                                if (xin) {
-                                    V.gmean[(size_t)y * w + x] = m.x;
-                                    V.gcinv[(size_t)y * w + x] = c;
-                                    if (V.mean_u8) {           // flToChOnGPU :451-458
-                                        int ci8 = (int)m.x;
-                                        V.mean_u8[(size_t)y * w + x] = (ci8 > 255) ? 255 : (uint8_t)ci8;
-                                    }
-                                }
-                            } else {
-                                float mm = ga * m.x;           // compute_ak_and_bk guidedFilter.cu:345-354
-                                float ak = 1.0f * (m.y - mm) * gb;
-                                float mb2 = 1.0f * ga * ak;
-                                float bk = 1.0f * m.x - mb2;
-                                f2 ab = {ak, bk};
-                                ring2[(y % RR) * PITCH + HW + lane] = ab;
-                                if (succ && lane >= OW - HW)
-                                    st_sc1(h_out, ((unsigned)y * HWMAX + (unsigned)(lane - (OW - HW))) * 8u, ab);
-                            }
+                if (succ && lane == 0 && i >= -1) flag_store(myflag, (unsigned)(2 * i + 2));
+                if (MODE == AGG && pred) {
+                    // halo columns + stage-2 carries loaded at B(i-1) -> ring 2 / staging
+#pragma unroll
+                    for (int e = 0; e < NHU; ++e) {
+                        const int r = hu_r[e], c = hu_c[e];
+                        if (r < hhi - hlo && c < HW) {
+                            int rr = hlo % RR + r;
+                            rr = rr >= RR ? rr - RR : rr;
+                            f2* dst = ring2 + rr * PITCH + c;
+                            dst[0] = lo2(hreg[e]);
+                            if (c + 1 < HW) dst[1] = hi2(hreg[e]);
                         }
                     }
-                    if (MODE == AGG && hact) ring2[(hy2 % RR) * PITCH + hj] = hv;
+                    if (lane < BH / 2) *(f4*)&cin[1][2 * lane] = c2reg;
                 }
-                drain_vmem();
-            }
-            __syncthreads();
-            // -------------------------------- step B(i) -----------------------------------------
-            if (wave == W_R) {
+                if (MODE == AGG && succ && i - 1 >= 0 && i - 1 < NB) {
+                    // stage-2 carries of band i-1 (row scan at B(i-1)) -> global
+                    if (lane < BH / 2)
+                        st16_sc1(r_out, (unsigned)(((i - 1) * REC_F2 + BH) * 8 + lane * 16), *(const f4*)&cout[1][2 * lane]);
+                }
+                if (pred && i + 2 < NB) {
+                    // stage-1 carries for the row scan of band i+2 at A(i+1): load now
+                    wait_pred(2 * i + 6);
+                    if (lane < BH / 2) c1reg = ld16_sc1(r_in, (unsigned)((i + 2) * REC_F2 * 8 + lane * 16));
+                }
                 if (MODE == AGG) {
-                    const int b = i;                       // row scan, stage 2
-                    const int ylo = max(0, b * BH - R), yhi = min(h, b * BH + BH - R);
-                    if (b >= 0 && ylo < yhi) rowscan(ring2, ylo, yhi - ylo, jlo2, jhi2, c2_in, c2_out);
-                    drain_vmem();
+                    rows2(i - 1, lo, hi);                  // column scan, stage 2, columns 64 ..
+                    if (i - 1 == 0) S2 = ident;
+                    if (ccol) colscan(ring2, lane + 64, lo, hi, S2);
                 }
-            } else if (wave == W_C) {
-                const int b = i + 1;                       // column scan, stage 1
-                if (b < NB && b * BH < h) {
-                    if (b == 0) { S1a = ident; S1b = ident; }
-                    colscan(ring1, b * BH, min(h, b * BH + BH), S1a, S1b);
+                V3_STAMP(0);
+                wg_barrier();
+                V3_STAMP(1);
+                // ------------------------------ step B(i), t = 2i + 5 ---------------------------
+                drain_vmem();
+                if (succ && lane == 0 && i >= -1) flag_store(myflag, (unsigned)(2 * i + 3));
+                if (pred && lane < BH / 2) *(f4*)&cin[0][2 * lane] = c1reg;
+                // stage-1 carries of band i+1 (row scan at A(i)) and halo columns of band i -> global
+                if (succ) {
+                    if (i + 1 >= 0 && i + 1 < NB && lane < BH / 2)
+                        st16_sc1(r_out, (unsigned)((i + 1) * REC_F2 * 8 + lane * 16), *(const f4*)&cout[0][2 * lane]);
+                    if (MODE == AGG && i >= 0 && i < NB) {
+#pragma unroll
+                        for (int e = 0; e < NHU; ++e) {
+                            const int t = lane + 64 * e;
+                            if (t < BH * HP / 2)
+                                st16_sc1(r_out, (unsigned)((i * REC_F2 + 2 * BH) * 8 + t * 16), *(const f4*)&hout[2 * t]);
+                        }
+                    }
                 }
-            } else {
-                uint32_t ua[NE], ub[NE];
-                const int be = i + 2;                      // stage-1 inputs two bands ahead
+                // stage-2 carries + halo columns of band i+1 (used at B(i+1) / A(i+1)): load now
+                if (MODE == AGG && pred) {
+                    rows2(i + 1, lo, hi);
+                    hlo = lo; hhi = hi;
+                    if (lo < hi && i + 1 < NB) {
+                        wait_pred(2 * i + 7);
+                        if (lane < BH / 2) c2reg = ld16_sc1(r_in, (unsigned)(((i + 1) * REC_F2 + BH) * 8 + lane * 16));
+#pragma unroll
+                        for (int e = 0; e < NHU; ++e) {
+                            const int t = lane + 64 * e;
+                            if (t < BH * HP / 2)
+                                hreg[e] = ld16_sc1(r_in, (unsigned)(((i + 1) * REC_F2 + 2 * BH) * 8 + t * 16));
+                        }
+                    }
+                }
+                rows1(i + 1, lo, hi);                      // column scan, stage 1, columns 64 ..
+                if (i + 1 == 0) S1 = ident;
+                if (ccol) colscan(ring1, lane + 64, lo, hi, S1);
+                V3_STAMP(2);
+                wg_barrier();
+                V3_STAMP(3);
+            }
+            drain_vmem();
+            if (succ && lane == 0) flag_store(myflag, FLAG_DONE);
+        } else if (wave == W_C) {
+            // =====================================================================================
+            // column-scan wave: ring columns 0 .. 63 of both stages
+            // =====================================================================================
+            f2 S1 = ident, S2 = ident;
+            for (int i = -2; i <= NB + 1; ++i) {
+                int lo, hi;
+                if (MODE == AGG) {
+                    rows2(i - 1, lo, hi);                  // A(i): stage 2, band i-1
+                    if (i - 1 == 0) S2 = ident;
+                    colscan(ring2, lane, lo, hi, S2);
+                }
+                V3_STAMP(0);
+                wg_barrier();
+                V3_STAMP(1);
+                rows1(i + 1, lo, hi);                      // B(i): stage 1, band i+1
+                if (i + 1 == 0) S1 = ident;
+                colscan(ring1, lane, lo, hi, S1);
+                V3_STAMP(2);
+                wg_barrier();
+                V3_STAMP(3);
+            }
+        } else if (wave == W_R) {
+            // =====================================================================================
+            // row-scan wave (LANE = ROW): 16-byte LDS accesses (two columns each), the reads of the
+            // next 8 columns are issued before the adds of the current 8
+            // =====================================================================================
+            const int jlo1 = max(0, -cs1), jhi1 = min(TW, w - cs1);   // ring-1 columns inside the image
+            const int jlo2 = max(0, -cs2), jhi2 = min(TW, w - cs2);
+            auto rowscan = [&](f2* ring, int st, int ylo, int yhi, int jlo, int jhi) {
+                if (lane >= yhi - ylo || jhi <= jlo) return;
+                const int y = ylo + lane;
+                f2 acc = pred ? cin[st][lane] : ident;
+                f2* row = ring + (y % RR) * PITCH;
+                int j = jlo;
+                if (j & 1) {
+                    acc = row[j] + acc;
+                    row[j] = acc;
+                    ++j;
+                }
+                // batches of 8 columns, ping-pong: the reads of the next batch are always issued (past
+                // the end they fetch bytes nobody uses: LDS reads cannot fault) so that the wait before
+                // the adds is a constant count and the scheduler keeps one batch of reads in flight
+                const int nb8 = (jhi - j) >> 3;
+                f4 va[4], vb[4];
+                auto rd = [&](f4 (&v)[4], int c) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = *(const f4*)(row + c + 2 * t);
+                };
+                auto run = [&](const f4 (&v)[4], int c) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const f2 s0 = lo2(v[t]) + acc;
+                        const f2 s1 = hi2(v[t]) + s0;
+                        acc = s1;
+                        const f4 o = {s0.x, s0.y, s1.x, s1.y};
+                        *(f4*)(row + c + 2 * t) = o;
+                    }
+                };
+                if (nb8 > 0) rd(va, j);
+                int b = 0;
+                for (; b + 2 <= nb8; b += 2) {
+                    rd(vb, j + 8);
+                    run(va, j);
+                    rd(va, j + 16);
+                    run(vb, j + 8);
+                    j += 16;
+                }
+                if (b < nb8) {
+                    run(va, j);
+                    j += 8;
+                }
+                for (; j < jhi; ++j) {
+                    acc = row[j] + acc;
+                    row[j] = acc;
+                }
+                // running row sum left of the next strip's first column
+                if (OW - 1 >= jlo && OW - 1 < jhi) cout[st][lane] = row[OW - 1];
+            };
+            for (int i = -2; i <= NB + 1; ++i) {
+                int lo, hi;
+                rows1(i + 1, lo, hi);                      // A(i): stage 1, band i+1
+                rowscan(ring1, 0, lo, hi, jlo1, jhi1);
+                V3_STAMP(0);
+                wg_barrier();
+                V3_STAMP(1);
+                if (MODE == AGG) {                         // B(i): stage 2, band i
+                    rows2(i, lo, hi);
+                    rowscan(ring2, 1, lo, hi, jlo2, jhi2);
+                }
+                V3_STAMP(2);
+                wg_barrier();
+                V3_STAMP(3);
+            }
+        } else {
+            // =====================================================================================
+            // box / eval waves (LANE = COLUMN); wave wb owns rows 2 wb and 2 wb + 1 of every band
+            // =====================================================================================
+            const int d = V.d0 + slice;
+            const fg_t* __restrict__ FG1 = V.FG1;
+            const fg_t* __restrict__ FG2 = V.FG2;
+            const unsigned fgw = (unsigned)w + 2;
+            // per-lane window geometry in x: fixed for the whole item
+            struct Geo { int jmax, jmin, xcw, xc; bool hx, xin; };
+            auto mkgeo = [&](int x, int cs) {
+                Geo g;
+                g.xin = x >= 0 && x < w;
+                g.xc = min(max(x, 0), w - 1);
+                const int xmax = min(w - 1, g.xc + R), xmn = g.xc - R - 1;
+                g.hx = xmn >= 0;
+                g.xcw = xmax - (g.hx ? xmn : -1);
+                g.jmax = min(max(xmax - cs, 0), TW - 1);
+                g.jmin = min(max(xmn - cs, 0), TW - 1);
+                return g;
+            };
+            const Geo g1 = mkgeo(xs + lane, cs1);
+            const Geo g2 = mkgeo(xs - R + lane, cs2);
+            // all 64 windows of the strip unclipped in x: no selects, one area per row
+            const bool xint1 = xs - R - 1 >= 0 && xs + OW - 1 + R <= w - 1;
+            const bool xint2 = xs - 2 * R - 1 >= 0 && xs + OW - 1 <= w - 1;
+            // box mean of row y (computeBoxFilterOnGPU guidedFilter.cu:305-318: S11 - S10 - S01 + S00
+            // in that order, then a true division by the clipped window area)
+            auto boxrow = [&](const f2* ring, const Geo& g, bool xint, int y) -> f2 {
+                const int ymax = min(h - 1, y + R);
+                const int ymin = y - R - 1;
+                const bool hy = ymin >= 0;
+                const int ych = ymax - (hy ? ymin : -1);
+                const f2* r1 = ring + (ymax % RR) * PITCH;
+                const f2 s11 = r1[g.jmax], s10 = r1[g.jmin];
+                f2 val;
+                if (xint) {
+                    val = s11 - s10;
+                    if (hy) {
+                        const f2* r0 = ring + (ymin % RR) * PITCH;
+                        const f2 s01 = r0[g.jmax], s00 = r0[g.jmin];
+                        val = val - s01;
+                        val = val + s00;
+                    }
+                    const int ai = HW * ych;
+                    return box_div(val, (float)ai, rcp_s[ai]);
+                }
+                val = s11;
+                f2 t = val - s10;
+                val = g.hx ? t : val;
+                if (hy) {
+                    const f2* r0 = ring + (ymin % RR) * PITCH;
+                    const f2 s01 = r0[g.jmax], s00 = r0[g.jmin];
+                    val = val - s01;
+                    t = val + s00;
+                    val = g.hx ? t : val;
+                }
+                const int ai = g.xcw * ych;
+                return box_div(val, (float)ai, rcp_s[ai]);
+            };
+            // stage-1 input cells of this lane, fixed for the item: rows 2wb, 2wb+1 at ring column
+            // `lane`, and row 2wb + (lane >> 5) at ring column 64 + (lane & 31).  Loads are clamped into
+            // the image instead of predicated: cells outside it are written but never accumulated.
+            constexpr int NE = 3;
+            unsigned e_v1[NE], e_v2[NE];     // byte offsets inside the row of this view / the partner
+            int e_ro[NE];                    // ring offset (float2) relative to the band's first row
+            const int rsel = lane >> 5;      // row of the third cell
+            const bool e2_ok = (lane & 31) < HW;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int j = e < 2 ? lane : 64 + (lane & 31);
+                const int r = e < 2 ? 2 * wb + e : 2 * wb + rsel;
+                const int c = min(max(cs1 + j, 0), w - 1);
+                e_ro[e] = r * PITCH + min(j, PITCH - 1);
+                e_v1[e] = (unsigned)(c + 1) * 4u;
+                if (SRC == SRC_IMG) {
+                    int xx = c + d;
+                    xx = xx < -1 ? -1 : (xx > w ? w : xx);   // sentinel columns
+                    e_v2[e] = (unsigned)(xx + 1) * 4u;
+                } else {
+                    e_v2[e] = (unsigned)c * 4u;
+                }
+            }
+            uint32_t ua[NE], ub[NE];
+            float ga[2], gb[2], Iv[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) { ga[t] = 0.0f; gb[t] = 0.0f; Iv[t] = 0.0f; }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { ua[e] = 0; ub[e] = 0; }
+
+            for (int i = -2; i <= NB + 1; ++i) {
+                int ylo, yhi;
+                // ------------------------------ step A(i) -----------------------------------------
+                // loads consumed in step B(i): guidance image of the q rows, stage-1 inputs of band i+2
+                const int be = i + 2;
                 const bool ev = be < NB && be * BH < h;
-                if (ev) e1_issue(be, ua, ub);
                 if (MODE == AGG) {
-                    const int b = i - 1;                   // box means of stage 2 -> q
-                    const int ylo = max(0, b * BH - 2 * R), yhi = min(h, b * BH + BH - 2 * R);
-                    const int x = xs - R + lane;
-                    if (b >= 0 && ylo < yhi) {
-                        const bool xin = x >= 0 && x < w;
-                        const int xc = min(max(x, 0), w - 1);
-                        float* __restrict__ qp = V.q + (size_t)slice * h * w;
-                        for (int y = ylo + wb; y < yhi; y += NWB) {
-                            const float I = (float)FG1[(size_t)y * fgw + xc + 1].x;
-                            const f2 m = box(ring2, cs2, xc, y);
-                            float tq = m.x * I;                // compute_q guidedFilter.cu:363-369
-                            if (xin) __builtin_nontemporal_store(tq + m.y, &qp[(size_t)y * w + x]);
+                    rows3(i - 1, ylo, yhi);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int y = ylo + 2 * wb + t;
+                        if (y < yhi) Iv[t] = (float)FG1[(size_t)y * fgw + g2.xc + 1].x;
+                    }
+                }
+                if (ev) {
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        // image row of the cell, clamped into the image (wave-uniform for e < 2)
+                        const int y = e < 2 ? min(be * BH + 2 * wb + e, h - 1) : min(be * BH + 2 * wb + rsel, h - 1);
+                        const char* b1 = (const char*)(FG1 + (size_t)y * fgw);
+                        ua[e] = *(const uint32_t*)(b1 + e_v1[e]);
+                        if (MODE == AGG && SRC == SRC_IMG)
+                            ub[e] = *(const uint32_t*)((const char*)(FG2 + (size_t)y * fgw) + e_v2[e]);
+                        if (MODE == AGG && SRC == SRC_COST)
+                            ub[e] = *(const uint32_t*)((const char*)(V.cost + ((size_t)slice * h + y) * w) + e_v2[e]);
+                    }
+                }
+                // box means of stage 1, band i (guidance statistics loaded in step B(i-1))
+                rows2(i, ylo, yhi);
+                if (ylo < yhi && xs < w) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int y = ylo + 2 * wb + t;
+                        if (y >= yhi) break;
+                        const f2 m = boxrow(ring1, g1, xint1, y);
+                        if (MODE == GUID) {
+                            float mm = m.x * m.x;          // pixelMultOnGPU(mean, mean) guidedFilter.cu:112
+                            float var = m.y - mm;          // pixelSousOnGPU :121
+                            float c = (float)(1.0f / ((double)var + A.eps));   // :350
+                            if (g1.xin) {
+                                const size_t o = (size_t)y * w + g1.xc;
+                                V.gmean[o] = m.x;
+                                V.gcinv[o] = c;
+                                if (V.mean_u8) {           // flToChOnGPU :451-458
+                                    int ci8 = (int)m.x;
+                                    V.mean_u8[o] = (ci8 > 255) ? 255 : (uint8_t)ci8;
+                                }
+                            }
+                        } else {
+                            float mm = ga[t] * m.x;        // compute_ak_and_bk guidedFilter.cu:345-354
+                            float ak = 1.0f * (m.y - mm) * gb[t];
+                            float mb2 = 1.0f * ga[t] * ak;
+                            float bk = 1.0f * m.x - mb2;
+                            f2 ab = {ak, bk};
+                            ring2[(y % RR) * PITCH + HW + lane] = ab;
+                            if (lane >= OW - HW) hout[(y - ylo) * HP + lane - (OW - HW)] = ab;
                         }
                     }
                 }
-                if (ev) e1_finish(be, ua, ub);
+                V3_STAMP(0);
+                wg_barrier();
+                V3_STAMP(1);
+                // ------------------------------ step B(i) -----------------------------------------
+                // loads consumed in step A(i+1): guidance statistics of the a/b rows of band i+1
+                if (MODE == AGG && xs < w) {
+                    rows2(i + 1, ylo, yhi);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int y = ylo + 2 * wb + t;
+                        if (y < yhi) {
+                            ga[t] = V.mean[(size_t)y * w + g1.xc];
+                            gb[t] = V.cinv[(size_t)y * w + g1.xc];
+                        }
+                    }
+                }
+                if (MODE == AGG) {                         // box means of stage 2 -> q of band i-1
+                    rows3(i - 1, ylo, yhi);
+                    if (ylo < yhi) {
+                        float* __restrict__ qp = V.q + (size_t)slice * h * w;
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const int y = ylo + 2 * wb + t;
+                            if (y >= yhi) break;
+                            const f2 m = boxrow(ring2, g2, xint2, y);
+                            float tq = m.x * Iv[t];        // compute_q guidedFilter.cu:363-369
+                            if (g2.xin) __builtin_nontemporal_store(tq + m.y, &qp[(size_t)y * w + g2.xc]);
+                        }
+                    }
+                }
+                if (ev) {                                  // stage-1 inputs of band i+2 -> ring 1
+                    f2* rb = ring1 + ((be * BH) % RR) * PITCH;
+#pragma unroll
+                    for (int e = 0; e < NE; ++e) {
+                        const fg_t q1 = __builtin_bit_cast(fg_t, ua[e]);
+                        f2 v;
+                        if (MODE == GUID) {
+                            v.x = (float)q1.x;            // chToFlOnGPU guidedFilter.cu:442-449
+                            v.y = v.x * v.x;              // pixelMultOnGPU(d_im, d_im) :111
+                        } else if (SRC == SRC_IMG) {
+                            v = cost_pair(q1, __builtin_bit_cast(fg_t, ub[e]), cc);
+                        } else {
+                            v.x = __builtin_bit_cast(float, ub[e]);   // copyFromBigToLittleOnGPU :198
+                            v.y = (float)q1.x * v.x;                  // pixelMultOnGPU(d_im, d_p) :209
+                        }
+                        if (e < 2 || e2_ok) rb[e_ro[e]] = v;
+                    }
+                }
+                V3_STAMP(2);
+                wg_barrier();
+                V3_STAMP(3);
             }
         }
         __syncthreads();
-        if (tid == 0 && succ) flag_store(myflag, (unsigned)(NB + 2));
     }
 }
 
@@ -561,8 +782,7 @@ struct V3Layout {
     int K, NB;
     size_t fg;        // floats per image plane (half2 = 4 B per pixel)
     size_t plane;     // floats per w*h plane
-    size_t sv_carry;  // floats of carry scratch per slice-view
-    size_t sv_halo;   // floats of halo scratch per slice-view
+    size_t sv_hand;   // floats of hand-off records per slice-view (2 parities x NB bands)
 };
 
 static V3Layout v3_layout(int w, int h, int R) {
@@ -571,8 +791,7 @@ static V3Layout v3_layout(int w, int h, int R) {
     L.NB = (h + 2 * R + v3::BH - 1) / v3::BH;
     L.fg = (size_t)(w + 2) * h;
     L.plane = (size_t)w * h;
-    L.sv_carry = (size_t)2 * 2 * h * 2;              // parity x stage x rows x float2
-    L.sv_halo = (size_t)2 * h * v3::HWMAX * 2;       // parity x rows x columns x float2
+    L.sv_hand = (size_t)2 * L.NB * v3::REC_F2 * 2;   // parity x bands x record x float2
     return L;
 }
 
@@ -590,10 +809,10 @@ size_t v3_workspace_bytes(int w, int h, int nslices) {
     size_t b = 0;
     b += 2 * align_up(L.fg * 4, 256);                               // both image planes (single-view calls too)
     b += 2 * align_up(L.plane * 4, 256);                            // mean_I, 1/(var+eps)
-    b += align_up((L.sv_carry + L.sv_halo) * 4, 256);               // guidance scratch
+    b += align_up(L.sv_hand * 4, 256);                              // guidance hand-off records
     b += v3_flag_bytes(L, 2);                                       // guidance control block (shared)
     b += (size_t)nslices * align_up(L.plane * 4, 256);              // q
-    b += align_up((size_t)nslices * (L.sv_carry + L.sv_halo) * 4, 256);
+    b += align_up((size_t)nslices * L.sv_hand * 4, 256);
     b += v3_flag_bytes(L, 2 * nslices);                             // control block (shared by both views)
     return b + 16 * 256;
 }
@@ -612,6 +831,14 @@ static int launch_walk3(const v3::Args& a, hipStream_t st) {
 // Aggregation + WTA of slices [s_begin, s_end) of `nviews` (1 or 2) views.  View v uses d_guide[v]
 // as guidance; its cost slices are d_cost[v] (materialised, slice s at (s - s_begin)*w*h) or, when
 // d_cost[v] == NULL, are built on the fly against d_guide[v ^ 1] (nviews == 2) / d_other[0].
+#ifdef SMX_V3_STAMPS
+extern "C" __attribute__((visibility("default"))) int smx_debug_read_stamps(unsigned long long* out, int n) {
+    const int m = v3::NWAVE * v3::STAMP_SLOTS;
+    SMX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(v3::g_stamps), sizeof(unsigned long long) * (n < m ? n : m)));
+    return m;
+}
+#endif
+
 // status word of the last fused aggregation that used this workspace (0 = ok)
 int v3_read_status(const void* d_ws, unsigned* out) {
     const char* base = (const char*)align_up((size_t)d_ws, 256);
@@ -649,13 +876,12 @@ int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     float *meanI[2], *cinv[2];
     for (int i = 0; i < 2; ++i) FG[i] = (v3::fg_t*)carve(L.fg * 4);
     for (int v = 0; v < nviews; ++v) { meanI[v] = (float*)carve(L.plane * 4); cinv[v] = (float*)carve(L.plane * 4); }
-    v3::f2* gcarry = (v3::f2*)carve((size_t)nviews * L.sv_carry * 4);
-    v3::f2* ghalo = (v3::f2*)carve(256);   // unused by the single-stage mode
+    v3::f2* ghand = (v3::f2*)carve((size_t)nviews * L.sv_hand * 4);
     char* gctrl = (char*)carve(v3_flag_bytes(L, nviews));
     const int total = s_end - s_begin;
     // per slice-view: q plane (unless the caller's volume is written directly) + scratch + flags
     const bool own_q = !(d_agg && d_agg[0]);
-    const size_t per_sv = (own_q ? align_up(L.plane * 4, 256) : 0) + (L.sv_carry + L.sv_halo) * 4 +
+    const size_t per_sv = (own_q ? align_up(L.plane * 4, 256) : 0) + L.sv_hand * 4 +
                           (size_t)L.K * sizeof(unsigned);
     size_t fit = avail > 8 * 256 + V3_CTRL_BYTES ? (avail - 8 * 256 - V3_CTRL_BYTES) / (per_sv * nviews) : 0;
     if (oom || (fit < 1 && total > 0))
@@ -667,8 +893,7 @@ int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     float* qbuf[2] = {nullptr, nullptr};
     if (own_q)
         for (int v = 0; v < nviews; ++v) qbuf[v] = (float*)carve((size_t)chunk * align_up(L.plane * 4, 256));
-    v3::f2* carry = (v3::f2*)carve((size_t)nsv_max * L.sv_carry * 4);
-    v3::f2* halo = (v3::f2*)carve((size_t)nsv_max * L.sv_halo * 4);
+    v3::f2* hand = (v3::f2*)carve((size_t)nsv_max * L.sv_hand * 4);
     char* ctrl = (char*)carve(v3_flag_bytes(L, nsv_max));
     if (oom) return fail(SMX_E_WS, "aggregate_v3: workspace carve overflow");
     // plane stride of q: w*h floats exactly (kernels index planes as slice*w*h), so the 256-B
@@ -701,7 +926,7 @@ int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             g.v[v].mean_u8 = d_mean_u8 ? d_mean_u8[v] : nullptr;
         }
         g.nslices = 1; g.nsv = nviews; g.nitems = nviews * L.K;
-        g.carry = gcarry; g.halo = ghalo;
+        g.hand = ghand;
         g.ticket = (unsigned*)gctrl; g.status = status;
         g.flags = (unsigned*)(gctrl + V3_CTRL_BYTES);
         SMX_HIP(hipMemsetAsync(gctrl, 0, v3_flag_bytes(L, nviews), st));
@@ -724,7 +949,7 @@ int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             wa.keys[v] = d_keys[vv];
         }
         a.nslices = cnt; a.nsv = cnt * nviews; a.nitems = a.nsv * L.K;
-        a.carry = carry; a.halo = halo;
+        a.hand = hand;
         a.ticket = (unsigned*)ctrl; a.status = status;
         a.flags = (unsigned*)(ctrl + V3_CTRL_BYTES);
         SMX_HIP(hipMemsetAsync(ctrl, 0, v3_flag_bytes(L, a.nsv), st));
