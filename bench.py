@@ -38,7 +38,6 @@ def main():
     ap.add_argument("--workload", default="kitti", choices=["tsukuba", "kitti", "motorcycle", "4k"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--slices-in-flight", type=int, default=None)
-    ap.add_argument("--pipeline", type=int, default=None, help="slice sub-chunks pipelined over streams")
     args = ap.parse_args()
 
     import numpy as np
@@ -63,8 +62,6 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     smx.lib()  # fail loudly if the HIP extension is missing
-    if args.pipeline is not None:
-        smx.lib().smx_set_agg_pipeline(args.pipeline)
     w, h, D = synth.SHAPES[args.workload]
     seed = synth.SEEDS.get(args.workload, 1)
     Il, Ir = synth.gen_pair(w, h, D, seed)

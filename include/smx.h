@@ -163,15 +163,15 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
  * invalid.  Not needed for correctness in normal operation. */
 int smx_dev_agg_status(const void* d_workspace);
 
-/* Aggregation implementation: 0 = auto (fused strip-walker kernels when the cost is built on the
- * fly and radius <= 9, else the multi-kernel path), 1 = force multi-kernel, 2 = force fused (error
- * if not applicable).  Process-wide; for tests and A/B timing.  smx_last_agg_path() reports which
- * one the last smx_dev_aggregate_wta call on this thread used (1 or 2). */
+/* Aggregation implementation: 0 = auto (the fused single-kernel aggregation when radius <= 9,
+ * else the multi-kernel path), 1 = force multi-kernel, 2 = force fused (error if radius > 9).
+ * Process-wide; for tests and A/B timing.  smx_last_agg_path() reports which one the last
+ * smx_dev_aggregate_wta[_pair] call on this thread used (1 or 2). */
 int smx_set_agg_path(int path);
 int smx_last_agg_path(void);
-/* Number of slice sub-chunks the fused path software-pipelines over its internal streams
- * (default 1 = everything on the caller's stream; 2-8 measured slower on one GPU).  Process-wide. */
-int smx_set_agg_pipeline(int subchunks);
+/* Tile geometry of the fused aggregation for a box radius: output columns per strip, rows per band,
+ * columns computed per strip (strip_cols + 2*radius + 1).  For tests that aim at tile boundaries. */
+int smx_agg_geometry(int radius, int* strip_cols, int* band_rows, int* tile_cols);
 
 /* winner_take_all.cuh (live WTA = dispSelectOnGPU, guidedFilter.cu:403-411), packed form. */
 int smx_dev_init_keys(uint64_t* d_keys, int64_t n, void* stream);

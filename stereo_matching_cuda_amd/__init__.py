@@ -13,7 +13,7 @@ Layout
 Importing the package does not load the HIP library; the first compute call does, and fails
 loudly if it has not been built.
 """
-from ._lib import Params, SmxError, build, default_params, lib  # noqa: F401
+from ._lib import Params, SmxError, build, check, default_params, lib  # noqa: F401
 from .stages import (compute_cost, compute_guided_filter, detect_occlusion,  # noqa: F401
                      fill_occlusion, init_wta, integral, rgb_to_grayscale, stereo_pair, write_mat)
 

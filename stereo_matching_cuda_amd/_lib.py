@@ -73,7 +73,7 @@ SIGNATURES = {
     "smx_unpack_key": (None, [_u64, C.POINTER(_f), C.POINTER(_u32)]),
     "smx_set_agg_path": (_i, [_i]),
     "smx_last_agg_path": (_i, []),
-    "smx_set_agg_pipeline": (_i, [_i]),
+    "smx_agg_geometry": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "smx_set_timing": (_i, [_i]),
     "smx_last_agg_ms": (_i, [C.POINTER(_f), C.POINTER(_i)]),
 }

@@ -558,39 +558,51 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             // all 64 windows of the strip unclipped in x: no selects, one area per row
             const bool xint1 = xs - R - 1 >= 0 && xs + OW - 1 + R <= w - 1;
             const bool xint2 = xs - 2 * R - 1 >= 0 && xs + OW - 1 <= w - 1;
-            // box mean of row y (computeBoxFilterOnGPU guidedFilter.cu:305-318: S11 - S10 - S01 + S00
-            // in that order, then a true division by the clipped window area)
-            auto boxrow = [&](const f2* ring, const Geo& g, bool xint, int y) -> f2 {
-                const int ymax = min(h - 1, y + R);
-                const int ymin = y - R - 1;
-                const bool hy = ymin >= 0;
-                const int ych = ymax - (hy ? ymin : -1);
-                const f2* r1 = ring + (ymax % RR) * PITCH;
-                const f2 s11 = r1[g.jmax], s10 = r1[g.jmin];
-                f2 val;
-                if (xint) {
-                    val = s11 - s10;
-                    if (hy) {
-                        const f2* r0 = ring + (ymin % RR) * PITCH;
-                        const f2 s01 = r0[g.jmax], s00 = r0[g.jmin];
-                        val = val - s01;
-                        val = val + s00;
+            // box means of two rows (computeBoxFilterOnGPU guidedFilter.cu:305-318: S11 - S10 - S01 + S00
+            // in that order, then a true division by the clipped window area).  Branch-free: all ten
+            // LDS reads are issued before the first use; clipped taps are read from a valid dummy
+            // address and dropped by a select; the exact-division fix-up is one rare branch at the end.
+            auto box2 = [&](const f2* ring, const Geo& g, bool xint, const int (&yy)[2], f2 (&m)[2]) {
+                f2 s11[2], s10[2], s01[2], s00[2], val[2];
+                float area[2], ra[2];
+                bool hy[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int ymax = min(h - 1, yy[t] + R);
+                    const int ymin = yy[t] - R - 1;
+                    hy[t] = ymin >= 0;
+                    const int ych = ymax - (hy[t] ? ymin : -1);
+                    const f2* r1 = ring + (ymax % RR) * PITCH;
+                    const f2* r0 = ring + ((hy[t] ? ymin : 0) % RR) * PITCH;
+                    s11[t] = r1[g.jmax]; s10[t] = r1[g.jmin];
+                    s01[t] = r0[g.jmax]; s00[t] = r0[g.jmin];
+                    const int ai = (xint ? HW : g.xcw) * ych;
+                    area[t] = (float)ai;
+                    ra[t] = rcp_s[ai];
+                }
+                bool slow = false;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f2 v = s11[t];
+                    f2 u = v - s10[t];
+                    v = (xint || g.hx) ? u : v;
+                    u = v - s01[t];
+                    v = hy[t] ? u : v;
+                    u = v + s00[t];
+                    v = (hy[t] && (xint || g.hx)) ? u : v;
+                    val[t] = v;
+                    m[t].x = div_small_int(v.x, area[t], ra[t]);
+                    m[t].y = div_small_int(v.y, area[t], ra[t]);
+                    slow = slow || div_needs_exact(v.x) || div_needs_exact(v.y);
+                }
+                if (__any(slow)) {
+                    asm volatile("; exact-division slow path");   // keep this a real (rare) wave-uniform branch
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        m[t].x = 1.0f * val[t].x / area[t];
+                        m[t].y = 1.0f * val[t].y / area[t];
                     }
-                    const int ai = HW * ych;
-                    return box_div(val, (float)ai, rcp_s[ai]);
                 }
-                val = s11;
-                f2 t = val - s10;
-                val = g.hx ? t : val;
-                if (hy) {
-                    const f2* r0 = ring + (ymin % RR) * PITCH;
-                    const f2 s01 = r0[g.jmax], s00 = r0[g.jmin];
-                    val = val - s01;
-                    t = val + s00;
-                    val = g.hx ? t : val;
-                }
-                const int ai = g.xcw * ych;
-                return box_div(val, (float)ai, rcp_s[ai]);
             };
             // stage-1 input cells of this lane, fixed for the item: rows 2wb, 2wb+1 at ring column
             // `lane`, and row 2wb + (lane >> 5) at ring column 64 + (lane & 31).  Loads are clamped into
@@ -651,33 +663,44 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 }
                 // box means of stage 1, band i (guidance statistics loaded in step B(i-1))
                 rows2(i, ylo, yhi);
-                if (ylo < yhi && xs < w) {
+                if (ylo + 2 * wb < yhi && xs < w) {
+                    // both rows in one straight-line block (the second one clamped onto the first when
+                    // it does not exist, its stores predicated): their LDS reads overlap
+                    f2 m[2];
+                    int yy[2];
+                    bool ok[2];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const int y = ylo + 2 * wb + t;
-                        if (y >= yhi) break;
-                        const f2 m = boxrow(ring1, g1, xint1, y);
+                        ok[t] = ylo + 2 * wb + t < yhi;
+                        yy[t] = ok[t] ? ylo + 2 * wb + t : ylo + 2 * wb;
+                    }
+                    box2(ring1, g1, xint1, yy, m);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int y = yy[t];
                         if (MODE == GUID) {
-                            float mm = m.x * m.x;          // pixelMultOnGPU(mean, mean) guidedFilter.cu:112
-                            float var = m.y - mm;          // pixelSousOnGPU :121
+                            float mm = m[t].x * m[t].x;    // pixelMultOnGPU(mean, mean) guidedFilter.cu:112
+                            float var = m[t].y - mm;       // pixelSousOnGPU :121
                             float c = (float)(1.0f / ((double)var + A.eps));   // :350
-                            if (g1.xin) {
+                            if (g1.xin && ok[t]) {
                                 const size_t o = (size_t)y * w + g1.xc;
-                                V.gmean[o] = m.x;
+                                V.gmean[o] = m[t].x;
                                 V.gcinv[o] = c;
                                 if (V.mean_u8) {           // flToChOnGPU :451-458
-                                    int ci8 = (int)m.x;
+                                    int ci8 = (int)m[t].x;
                                     V.mean_u8[o] = (ci8 > 255) ? 255 : (uint8_t)ci8;
                                 }
                             }
                         } else {
-                            float mm = ga[t] * m.x;        // compute_ak_and_bk guidedFilter.cu:345-354
-                            float ak = 1.0f * (m.y - mm) * gb[t];
+                            float mm = ga[t] * m[t].x;     // compute_ak_and_bk guidedFilter.cu:345-354
+                            float ak = 1.0f * (m[t].y - mm) * gb[t];
                             float mb2 = 1.0f * ga[t] * ak;
-                            float bk = 1.0f * m.x - mb2;
+                            float bk = 1.0f * m[t].x - mb2;
                             f2 ab = {ak, bk};
-                            ring2[(y % RR) * PITCH + HW + lane] = ab;
-                            if (lane >= OW - HW) hout[(y - ylo) * HP + lane - (OW - HW)] = ab;
+                            if (ok[t]) {
+                                ring2[(y % RR) * PITCH + HW + lane] = ab;
+                                if (lane >= OW - HW) hout[(y - ylo) * HP + lane - (OW - HW)] = ab;
+                            }
                         }
                     }
                 }
@@ -699,15 +722,21 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 }
                 if (MODE == AGG) {                         // box means of stage 2 -> q of band i-1
                     rows3(i - 1, ylo, yhi);
-                    if (ylo < yhi) {
+                    if (ylo + 2 * wb < yhi) {
                         float* __restrict__ qp = V.q + (size_t)slice * h * w;
+                        f2 m[2];
+                        int yy[2];
+                        bool ok[2];
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            const int y = ylo + 2 * wb + t;
-                            if (y >= yhi) break;
-                            const f2 m = boxrow(ring2, g2, xint2, y);
-                            float tq = m.x * Iv[t];        // compute_q guidedFilter.cu:363-369
-                            if (g2.xin) __builtin_nontemporal_store(tq + m.y, &qp[(size_t)y * w + g2.xc]);
+                            ok[t] = ylo + 2 * wb + t < yhi;
+                            yy[t] = ok[t] ? ylo + 2 * wb + t : ylo + 2 * wb;
+                        }
+                        box2(ring2, g2, xint2, yy, m);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            float tq = m[t].x * Iv[t];     // compute_q guidedFilter.cu:363-369
+                            if (g2.xin && ok[t]) __builtin_nontemporal_store(tq + m[t].y, &qp[(size_t)yy[t] * w + g2.xc]);
                         }
                     }
                 }
@@ -794,6 +823,8 @@ static V3Layout v3_layout(int w, int h, int R) {
     L.sv_hand = (size_t)2 * L.NB * v3::REC_F2 * 2;   // parity x bands x record x float2
     return L;
 }
+
+void v3_geometry(int* ow, int* bh) { *ow = v3::OW; *bh = v3::BH; }
 
 bool v3_supported(const smx_params* p) { return p->radius >= 0 && p->radius <= v3::RMAX; }
 

@@ -14,17 +14,9 @@ static thread_local bool g_timing = false;
 static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static thread_local bool g_ev_valid = false;
 static thread_local int g_launches = 0;
-static int g_agg_path = 0;                 // 0 auto, 1 multi-kernel, 2 fused (v3), 3 round-1 fused (v2, A/B only)
+static int g_agg_path = 0;                 // 0 auto, 1 force multi-kernel, 2 force fused
 static thread_local int g_last_path = 0;
 
-// smx_agg_v2.hip
-bool v2_supported(const smx_params* p);
-void v2_set_pipeline(int subchunks);
-size_t v2_workspace_bytes(int w, int h, int R, int nslices);
-int aggregate_v2(const smx_params* p, int nviews, const uint8_t* const* d_guide,
-                 const uint8_t* const* d_other, int w, int h, const int* dmin, int s_begin, int s_end,
-                 uint64_t* const* d_keys, uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws,
-                 size_t ws_bytes, hipStream_t st, int* launches);
 // smx_agg_v3.hip
 bool v3_supported(const smx_params* p);
 size_t v3_workspace_bytes(int w, int h, int nslices);
@@ -35,6 +27,7 @@ int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                  hipStream_t st, int* launches);
 
 int v3_read_status(const void* d_ws, unsigned* out);
+void v3_geometry(int* ow, int* bh);
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -73,7 +66,7 @@ void smx_default_params(smx_params* p) {
 
 const char* smx_last_error(void) { return g_err.c_str(); }
 
-const char* smx_version(void) { return "smx-hip gfx950 0.2 (fused strip-walker aggregation)"; }
+const char* smx_version(void) { return "smx-hip gfx950 0.3 (single-kernel fused guided-filter aggregation)"; }
 
 int smx_device_count(void) {
     int n = 0;
@@ -135,23 +128,25 @@ int smx_dev_integral(const float* d_in, float* d_out, int w, int h, int nplanes,
 size_t smx_agg_workspace_bytes(int w, int h, int nslices) {
     if (w < 1 || h < 1 || nslices < 1) return 0;
     // v1 path: guidance im, mean_im, cinv, S_im, S_sq ; per slice in flight: cost, T0, T1, A, B
-    const size_t v1 = plane_bytes(w, h) * (5 + 5 * (size_t)nslices) + WS_ALIGN;
-    const size_t v2b = v2_workspace_bytes(w, h, -1, nslices);
+    const size_t v1 = plane_bytes(w, h) * (5 + 5 * (size_t)nslices) + 2 * WS_ALIGN;
     const size_t v3b = v3_workspace_bytes(w, h, nslices);
-    const size_t m = v1 > v2b ? v1 : v2b;
-    return m > v3b ? m : v3b;
+    return v1 > v3b ? v1 : v3b;
 }
 
 int smx_set_agg_path(int path) {
-    if (path < 0 || path > 3) return fail(SMX_E_ARG, "smx_set_agg_path: path must be 0 .. 3");
+    if (path < 0 || path > 2) return fail(SMX_E_ARG, "smx_set_agg_path: path must be 0, 1 or 2");
     g_agg_path = path;
     return SMX_OK;
 }
 
 int smx_last_agg_path(void) { return g_last_path; }
 
-int smx_set_agg_pipeline(int subchunks) {
-    v2_set_pipeline(subchunks);
+int smx_agg_geometry(int radius, int* strip_cols, int* band_rows, int* tile_cols) {
+    int ow = 0, bh = 0;
+    v3_geometry(&ow, &bh);
+    if (strip_cols) *strip_cols = ow;
+    if (band_rows) *band_rows = bh;
+    if (tile_cols) *tile_cols = ow + 2 * radius + 1;
     return SMX_OK;
 }
 
@@ -203,34 +198,32 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
     hipStream_t st = (hipStream_t)stream;
     // fused path (smx_agg_v3.hip): radius <= 9; cost built on the fly or read from d_cost
     const bool can_v3 = v3_supported(p);
-    const bool can_v2 = !d_cost && d_other && v2_supported(p);
     if (g_agg_path == 2 && !can_v3)
         return fail(SMX_E_ARG, "smx_dev_aggregate_wta: fused path forced but radius > 9");
-    if (g_agg_path == 3 && !can_v2)
-        return fail(SMX_E_ARG, "smx_dev_aggregate_wta: round-1 fused path forced but not applicable");
-    if ((can_v3 && (g_agg_path == 0 || g_agg_path == 2)) || g_agg_path == 3) {
+    if (can_v3 && g_agg_path != 1) {
         g_launches = 0;
         if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
-        int rc2;
-        if (g_agg_path == 3)
-            rc2 = aggregate_v2(p, 1, &d_guide, &d_other, w, h, &dmin, s_begin, s_end, &d_keys,
-                               &d_mean_u8, &d_agg, d_workspace, workspace_bytes, st, &g_launches);
-        else
-            rc2 = aggregate_v3(p, 1, &d_guide, &d_other, &d_cost, w, h, &dmin, s_begin, s_end, &d_keys,
+        int rc2 = aggregate_v3(p, 1, &d_guide, &d_other, &d_cost, w, h, &dmin, s_begin, s_end, &d_keys,
                                &d_mean_u8, &d_agg, d_workspace, workspace_bytes, st, &g_launches);
         if (rc2) return rc2;
         if (g_timing) {
             SMX_HIP(hipEventRecord(g_ev1, st));
             g_ev_valid = true;
         }
-        g_last_path = g_agg_path == 3 ? 3 : 2;
+        g_last_path = 2;
         return SMX_OK;
     }
     g_last_path = 1;
     const size_t pb = plane_bytes(w, h);
     const int64_t n = (int64_t)w * h;
     char* base = (char*)align_up((size_t)d_workspace, WS_ALIGN);
-    size_t avail = workspace_bytes - (size_t)(base - (char*)d_workspace);
+    size_t avail = workspace_bytes > (size_t)(base - (char*)d_workspace) + WS_ALIGN
+                       ? workspace_bytes - (size_t)(base - (char*)d_workspace) - WS_ALIGN : 0;
+    if (avail >= pb * 10) {
+        // first 256 B: status word of the call (smx_dev_agg_status); this path cannot time out
+        SMX_HIP(hipMemsetAsync(base, 0, WS_ALIGN, st));
+        base += WS_ALIGN;
+    }
     if (workspace_bytes < WS_ALIGN || avail < pb * 10)
         return fail(SMX_E_WS, "smx_dev_aggregate_wta: workspace %zu B < %zu B needed for one slice",
                     workspace_bytes, smx_agg_workspace_bytes(w, h, 1));
@@ -304,13 +297,7 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
         float* agg[2] = {d_agg, d_agg ? d_agg + vol : nullptr};
         g_launches = 0;
         if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
-        int rc2;
-        if (g_agg_path == 3)
-            rc2 = aggregate_v2(p, 2, guide, other, w, h, dmin, s_begin, s_end, keys,
-                               d_mean_u8 ? mean : nullptr, d_agg ? agg : nullptr, d_workspace,
-                               workspace_bytes, st, &g_launches);
-        else
-            rc2 = aggregate_v3(p, 2, guide, other, nullptr, w, h, dmin, s_begin, s_end, keys,
+        int rc2 = aggregate_v3(p, 2, guide, other, nullptr, w, h, dmin, s_begin, s_end, keys,
                                d_mean_u8 ? mean : nullptr, d_agg ? agg : nullptr, d_workspace,
                                workspace_bytes, st, &g_launches);
         if (rc2) return rc2;
@@ -318,7 +305,7 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
             SMX_HIP(hipEventRecord(g_ev1, st));
             g_ev_valid = true;
         }
-        g_last_path = g_agg_path == 3 ? 3 : 2;
+        g_last_path = 2;
         return SMX_OK;
     }
     if (g_agg_path == 2)

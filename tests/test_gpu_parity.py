@@ -202,7 +202,7 @@ def test_pair_tsukuba_against_committed_outputs(tsukuba_gray, tsukuba_oracle, go
 
 
 def _device_pair(Il, Ir, D, path=2, **kw):
-    """path: 2 = fused strip-walker aggregation (the default product path), 1 = multi-kernel path."""
+    """path: 2 = fused single-kernel aggregation (the default product path), 1 = multi-kernel path."""
     import torch
     from stereo_matching_cuda_amd.device import PairPipeline
     h, w = Il.shape
@@ -226,27 +226,9 @@ def test_device_pipeline_tsukuba_fused_cost(tsukuba_gray, tsukuba_oracle, path):
         _eq(r[k], tsukuba_oracle[k], k)
 
 
-@pytest.mark.parametrize("subchunks", [1, 2, 7])
-def test_stream_pipelined_subchunks_give_identical_results(orc, subchunks):
-    """The fused path pipelines slice sub-chunks over internal streams (smx_set_agg_pipeline)."""
-    w, h, D = 300, 200, 70
-    rng = np.random.default_rng(99)
-    base = rng.integers(0, 256, size=(h, w + D), dtype=np.uint8)
-    Il = np.ascontiguousarray(base[:, :w])
-    Ir = np.ascontiguousarray(base[:, 20:20 + w])
-    want = orc.stereo_pair(Il, Ir, D)
-    smx.lib().smx_set_agg_pipeline(subchunks)
-    try:
-        r = _device_pair(Il, Ir, D)
-    finally:
-        smx.lib().smx_set_agg_pipeline(1)
-    for k in KEYS:
-        _eq(r[k], want[k], k)
-
-
 @pytest.mark.parametrize("radius,alpha,thc,thg,eps,dminl,dminr", [
     (9, 0.9, 7, 2, 6.5025, None, 0),       # reference defaults
-    (3, 0.9, 7, 2, 6.5025, None, 0),       # smaller window: wider strips, other carry segments
+    (3, 0.9, 7, 2, 6.5025, None, 0),       # smaller window: narrower tiles, other halo width
     (0, 0.5, 3, 1, 1.0, None, 0),          # degenerate 1x1 window; var + eps hits 0 -> NaN slices
     (5, 0.25, 20, 5, 0.01, -30, 7),        # other thresholds, ranges that do not start at 0
     (9, 0.9, 7, 2, 6.5025, -400, 380),     # every disparity points outside the image
@@ -323,12 +305,39 @@ def test_default_path_is_the_fused_one(tsukuba_gray):
     assert smx.lib().smx_last_agg_path() == 2
 
 
-@pytest.mark.parametrize("w,h,D", [(2, 1, 2), (20, 20, 3), (19, 40, 4), (64, 9, 2), (129, 70, 5),
-                                   (94, 65, 6), (113, 130, 7), (93, 64, 3), (187, 129, 20),
-                                   (300, 200, 70)])
+def _geometry(radius):
+    ow, bh, tw = C.c_int(), C.c_int(), C.c_int()
+    smx.check(smx.lib().smx_agg_geometry(radius, C.byref(ow), C.byref(bh), C.byref(tw)))
+    return ow.value, bh.value, tw.value
+
+
+def _ragged_shapes():
+    """Shapes aimed at the tile boundaries of the fused kernel, derived from its geometry constants
+    (smx_agg_geometry): widths around multiples of the strip width OW (w % OW in {0, 1, OW-1}, and
+    w + R crossing a strip count), heights around multiples of the band height BH (exact multi-band
+    heights, one row more / less, heights whose lagged stage-2 / q rows need an extra band)."""
+    # literal copies of the library constants; test_ragged_shapes_match_the_library_geometry pins them
+    OW, BH = 64, 26
+    ws = [2, OW - 1, OW, OW + 1, 2 * OW - 9, 2 * OW - 8, 2 * OW, 2 * OW + 1, 3 * OW - 1]
+    hs = [1, BH - 1, BH, BH + 1, 2 * BH, 2 * BH + 1, 3 * BH - 18, 3 * BH - 9, 3 * BH, 4 * BH + 7]
+    shapes = [(2, 1, 2), (20, 20, 3), (19, 40, 4), (300, 200, 70)]
+    for i, w in enumerate(ws):
+        shapes.append((w, hs[i % len(hs)], 3 + i % 5))
+    for i, h in enumerate(hs):
+        shapes.append((ws[(i + 3) % len(ws)], h, 2 + i % 4))
+    return sorted(set(shapes))
+
+
+def test_ragged_shapes_match_the_library_geometry():
+    assert _geometry(9) == (64, 26, 83)
+    assert _geometry(0) == (64, 26, 65)
+
+
+@pytest.mark.parametrize("w,h,D", _ragged_shapes())
 def test_fused_path_small_and_ragged(orc, w, h, D):
-    """Strip / sub-strip / band / ring boundaries of the fused kernels (TW=112, OW=93, SUBW=28,
-    BH=64, ring 84 rows), images smaller than one tile, disparity ranges wider than the image."""
+    """Strip / band / ring boundaries of the fused kernel (64 output columns per strip, 26-row bands,
+    78-row rings at the time of writing -- the shapes follow smx_agg_geometry), images smaller than
+    one tile, disparity ranges wider than the image."""
     rng = np.random.default_rng(w * 7 + h * 3 + D)
     base = rng.integers(0, 256, size=(h, w + D), dtype=np.uint8)
     Il = np.ascontiguousarray(base[:, :w])
@@ -337,6 +346,68 @@ def test_fused_path_small_and_ragged(orc, w, h, D):
     r = _device_pair(Il, Ir, D, want_agg=True)
     for k in KEYS + ("aggl", "aggr"):
         _eq(r[k], want[k], k)
+
+
+@pytest.mark.parametrize("radius,w,h", [(0, 128, 52), (0, 129, 53), (4, 64, 26), (4, 65, 78), (4, 192, 27)])
+def test_fused_path_small_radius_at_tile_edges(orc, radius, w, h):
+    """Radii other than 9 change the tile width (OW + 2R + 1), the halo width and the row lags."""
+    D = 5
+    rng = np.random.default_rng(radius * 100 + w + h)
+    base = rng.integers(0, 256, size=(h, w + D), dtype=np.uint8)
+    Il = np.ascontiguousarray(base[:, :w])
+    Ir = np.ascontiguousarray(base[:, 2:2 + w])
+    p = smx.default_params()
+    p.radius = radius
+    po = orc.Params.from_buffer_copy(bytes(p))
+    want = orc.stereo_pair(Il, Ir, D, want_agg=True, params=po)
+    r = _device_pair(Il, Ir, D, want_agg=True, params=p)
+    for k in KEYS + ("aggl", "aggr"):
+        _eq(r[k], want[k], k)
+
+
+def test_materialised_cost_volume_takes_the_fused_path(tsukuba_gray, tsukuba_oracle):
+    """The reference's calling convention (compute_guided_filter with a cost volume from compute_cost,
+    guidedFilter.cu:4-295) runs the same fused kernel, reading p instead of building it."""
+    import torch
+    from stereo_matching_cuda_amd.device import PairPipeline
+    Il, Ir = tsukuba_gray
+    dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
+    cl = torch.from_numpy(tsukuba_oracle["costl"]).cuda()
+    cr = torch.from_numpy(tsukuba_oracle["costr"]).cuda()
+    pipe = PairPipeline(384, 288, 16, dminl=-15, dminr=0, want_agg=True)
+    pipe.aggregate(dl, dr, cl, cr)
+    assert smx.lib().smx_last_agg_path() == 2
+    pipe.finish()
+    r = pipe.results()
+    for k in KEYS + ("aggl", "aggr"):
+        _eq(r[k], tsukuba_oracle[k], k)
+
+
+def test_pair_step_is_capturable_in_a_hip_graph(tsukuba_gray, tsukuba_oracle):
+    """include/smx.h: smx_dev_* do not allocate or synchronise -> one pair step can be captured
+    into a hipGraph and replayed; the replay must give the oracle's result."""
+    import torch
+    from stereo_matching_cuda_amd.device import PairPipeline
+    Il, Ir = tsukuba_gray
+    dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
+    pipe = PairPipeline(384, 288, 16, dminl=-15, dminr=0)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        pipe.run(dl, dr)                      # warm-up outside capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        pipe.run(dl, dr)
+    pipe.keys.zero_()
+    pipe.dmap.zero_()
+    pipe.filled.zero_()
+    for _ in range(2):
+        g.replay()
+    r = pipe.results()
+    for k in KEYS:
+        _eq(r[k], tsukuba_oracle[k], k)
 
 
 @pytest.mark.parametrize("path", [2, 1])
@@ -418,6 +489,72 @@ def test_pair_motorcycle_shape_properties():
         pipe.aggregate(dl, dr)
         k = pipe.keys_signed().clone()
         merged = k if merged is None else torch.minimum(merged, k)
+    pipe.keys.copy_(merged)
+    pipe.keys_unsigned()
+    assert torch.equal(pipe.keys, keys_full)
+    pipe.finish()
+    r = pipe.results()
+    for k in KEYS[2:]:
+        _eq(r[k], ref[k], k)
+
+
+def test_kitti_shape_virtual_shards_equal_the_oracle(orc):
+    """BASELINE config 4 (1242x375 D=192 disparity-sharded over 2/4/8 GPUs) on one device: G virtual
+    shards merged with the u64 min == the oracle's unsharded result, bit for bit."""
+    import torch
+    from stereo_matching_cuda_amd.device import PairPipeline
+    from stereo_matching_cuda_amd.sharded import shard_range
+    w, h, D = synth.SHAPES["kitti"]
+    Il, Ir = synth.gen_pair(w, h, D, synth.SEEDS["kitti"])
+    want = orc.stereo_pair(Il, Ir, D)
+    dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
+    for G in (2, 4, 8):
+        merged = None
+        for g in range(G):
+            s0, s1 = shard_range(D, g, G)
+            pipe = PairPipeline(w, h, D, s_begin=s0, s_end=s1)
+            pipe.aggregate(dl, dr)
+            k = pipe.keys_signed().clone()
+            merged = k if merged is None else torch.minimum(merged, k)
+        pipe.keys.copy_(merged)
+        pipe.keys_unsigned()
+        pipe.finish()
+        r = pipe.results()
+        for k in KEYS:
+            _eq(r[k], want[k], f"G={G} {k}")
+
+
+def test_pair_4k_shape_properties():
+    """BASELINE config 5 shape (3840x2160, D=512; 8 GPUs there, one GPU with a chunked workspace here)
+    through size-independent properties: 8 virtual shards == unsharded keys; a differently chunked
+    run == the same keys; labels inside their ranges; filling idempotent."""
+    import torch
+    from stereo_matching_cuda_amd.device import PairPipeline
+    from stereo_matching_cuda_amd.sharded import shard_range
+    w, h, D = synth.SHAPES["4k"]
+    Il, Ir = synth.gen_pair(w, h, D, synth.SEEDS["4k"])
+    dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
+    full = PairPipeline(w, h, D, slices_in_flight=128)
+    full.run(dl, dr)
+    ref = full.results()
+    keys_full = full.keys.clone()
+    assert ref["dmapl"].min() >= -(D - 1) and ref["dmapl"].max() <= 0
+    assert ref["dmapr"].min() >= 0 and ref["dmapr"].max() <= D - 1
+    again = smx.fill_occlusion(ref["filled"], float(-(D - 1)))
+    _eq(again, ref["filled"], "fill idempotent")
+    del full
+    torch.cuda.empty_cache()
+    merged = None
+    for g in range(8):
+        s0, s1 = shard_range(D, g, 8)
+        pipe = PairPipeline(w, h, D, s_begin=s0, s_end=s1, slices_in_flight=24)   # 64 slices, 3 chunks
+        pipe.aggregate(dl, dr)
+        pipe.check_status()
+        k = pipe.keys_signed().clone()
+        merged = k if merged is None else torch.minimum(merged, k)
+        if g < 7:
+            del pipe
+            torch.cuda.empty_cache()
     pipe.keys.copy_(merged)
     pipe.keys_unsigned()
     assert torch.equal(pipe.keys, keys_full)

@@ -1,23 +1,26 @@
 #!/usr/bin/env python3
-"""Turn a tools/pmc.sh run (gpurun_out/<dir>/p*/.../*counter_collection.csv) into the HBM-traffic
-figure bench.py reports as roofline.traffic.
+"""Turn the rocprofv3 --pmc passes of tools/gpu_suite.sh (gpurun_out/<tag>/pmc_FETCH_SIZE,
+pmc_WRITE_SIZE) into the HBM-traffic figure bench.py reports as roofline.traffic.
 
-  python tools/traffic.py gpurun_out/pmcN profiles/r01_traffic.json
+  python tools/traffic.py gpurun_out/<tag> [profiles/rNN_traffic.json]
 
-Per MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE come from separate --pmc passes,
-are in KiB, and on gfx950 FETCH_SIZE reports half of the bytes of a coalesced stream.  The factor is
-calibrated here on k_v2_carry<2>, which reads the a/b planes exactly once (known byte count)."""
+Per MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE come from separate --pmc passes
+and are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a coalesced stream.  The x2 is
+checked here on k_v3_wta, which reads the aggregated volumes exactly once (known byte count: the
+bench's 2 x 1242 x 375 x 192 floats + the key planes)."""
 import collections
 import csv
 import glob
 import json
 import sys
 
+AGG_KERNELS = ("k_v3_walk", "k_v3_wta", "k_v3_prep")
 
-def main(src, dst):
+
+def main(src, dst=None):
     tot = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(lambda: collections.defaultdict(int))
-    for f in glob.glob(src + "/p*/*/*counter_collection.csv"):
+    for f in glob.glob(src + "/pmc_*/*/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
@@ -28,20 +31,24 @@ def main(src, dst):
     for k in tot:
         f = tot[k]["FETCH_SIZE"] / max(1, cnt[k]["FETCH_SIZE"])
         w = tot[k]["WRITE_SIZE"] / max(1, cnt[k]["WRITE_SIZE"])
-        per[k] = {"fetch_kib_raw": f, "write_kib": w, "hbm_bytes": (2.0 * f + w) * 1024.0}
-    agg = [k for k in per if "v2::" in k]
+        per[k] = {"fetch_kib_raw": f, "write_kib": w, "hbm_bytes": (2.0 * f + w) * 1024.0,
+                  "dispatches_seen": cnt[k]["FETCH_SIZE"]}
+    agg = [k for k in per if any(a in k for a in AGG_KERNELS)]
     out = {
         "source": src,
         "method": "sum over the kernels of one smx_dev_aggregate_wta_pair call of "
-                  "(2*FETCH_SIZE + WRITE_SIZE)*1024; FETCH_SIZE x2 = gfx950 correction, calibrated on "
-                  "k_v2_carry<2> (reads a,b exactly once)",
+                  "(2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch; FETCH_SIZE x2 = gfx950 correction "
+                  "(MI355X_MICROARCH.md), checked on k_v3_wta (reads q exactly once)",
         "aggregation_call_hbm_bytes": sum(per[k]["hbm_bytes"] for k in agg),
         "kernels": {k: per[k] for k in sorted(per)},
     }
-    json.dump(out, open(dst, "w"), indent=1)
-    print(json.dumps({k: round(v["hbm_bytes"] / 1e6, 1) for k, v in per.items() if k in agg}, indent=1))
+    if dst:
+        json.dump(out, open(dst, "w"), indent=1)
+    for k in sorted(agg):
+        print(f"{k:60s} fetch_raw {per[k]['fetch_kib_raw']/1024:9.1f} MiB  write {per[k]['write_kib']/1024:9.1f} MiB"
+              f"  hbm {per[k]['hbm_bytes']/1e6:9.1f} MB")
     print("aggregation call HBM MB:", round(out["aggregation_call_hbm_bytes"] / 1e6, 1))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:3])
