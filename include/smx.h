@@ -94,6 +94,12 @@ int smx_detect_occlusion(const smx_params* p, float* disparityLeft, const float*
 /* occlusion.cuh:14  void fill_occlusion(float* disparity, w, h, vMin) ; in place. */
 int smx_fill_occlusion(float* disparity, int w, int h, float vMin);
 
+/* filter.cuh:12  void filter(image, width, height, mean, var, cuda)   (dead code in the reference:
+ * never called from main.cu).  Direct (2R+1)^2 box filter with zero padding, truncated means:
+ * mean = (uchar)(int)(sum(I)/(2R+1)^2); var = (float)(int)(sum(I*I)/(2R+1)^2) - mean*mean
+ * (filter.cu:39-115, 143-181).  mean: w*h bytes, var: w*h floats, caller-allocated. */
+int smx_filter(const smx_params* p, const uint8_t* image, int w, int h, uint8_t* mean, float* var);
+
 /* main.cu:65-155 as one call on two gray images (device-resident between stages).
  * Left volume labels dminl .. dminl+size_d-1, right volume dminr .. dminr+size_d-1
  * (main.cu:79-82).  Any output pointer may be NULL.  occlusion uses dOcclusion = dminl-100
@@ -136,14 +142,15 @@ size_t smx_agg_workspace_bytes(int w, int h, int nslices);
  *   d_other  : the other view; used to build cost slices on the fly when d_cost == NULL
  *              (costVolume.cu:163-190 fused in).  May be NULL when d_cost is given.
  *   d_cost   : optional materialised cost slices, slice s at d_cost[(s - s_begin)*w*h]
- *   d_keys   : n packed u64 WTA keys, IN/OUT: key = ord(cost)<<32 | (0xFFFFFFFF - slice);
- *              initialise with smx_dev_init_keys; min-combine across shards (all-reduce MIN)
+ *   d_keys   : n packed WTA keys, IN/OUT: key = sord(cost)<<32 | (0xFFFFFFFF - slice) compared as
+ *              signed 64-bit integers (sord = order-preserving f32 -> i32 map); initialise with
+ *              smx_dev_init_keys (INT64_MAX); combine across shards with an int64 MIN all-reduce
  *   d_mean_u8: optional u8 mean image out (guidedFilter.cu:87,122)
  *   d_agg    : optional aggregated slices out, slice s at d_agg[(s - s_begin)*w*h]
  * Slices are processed in chunks that fit the workspace (>= smx_agg_workspace_bytes(w,h,1)). */
 int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uint8_t* d_other,
                           const float* d_cost, int w, int h, int dmin, int s_begin, int s_end,
-                          uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
+                          int64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
                           size_t workspace_bytes, void* stream);
 
 /* Both views of a stereo pair in one call (main.cu:133-134 back to back): every kernel launch
@@ -153,7 +160,7 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
  * volumes of (s_end - s_begin)*n floats.  Workspace: >= 2 * smx_agg_workspace_bytes(w, h, nslices). */
 int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const uint8_t* d_right,
                                int w, int h, int dminl, int dminr, int s_begin, int s_end,
-                               uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
+                               int64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
                                size_t workspace_bytes, void* stream);
 
 /* Synchronous health check of the last smx_dev_aggregate_wta[_pair] call that used d_workspace:
@@ -174,21 +181,24 @@ int smx_last_agg_path(void);
 int smx_agg_geometry(int radius, int* strip_cols, int* band_rows, int* tile_cols);
 
 /* winner_take_all.cuh (live WTA = dispSelectOnGPU, guidedFilter.cu:403-411), packed form. */
-int smx_dev_init_keys(uint64_t* d_keys, int64_t n, void* stream);
+int smx_dev_init_keys(int64_t* d_keys, int64_t n, void* stream);
 /* Fold keys into best/dmap with the reference's rule: if (best >= q) { dmap = dmin + slice;
  * best = q; }.  best/dmap are IN/OUT (use smx_dev_init_wta for the reference's presets). */
-int smx_dev_apply_keys(const uint64_t* d_keys, int64_t n, int dmin, float* d_best, float* d_dmap,
+int smx_dev_apply_keys(const int64_t* d_keys, int64_t n, int dmin, float* d_best, float* d_dmap,
                        void* stream);
 /* main.cu:112-118: best <- 0x7F7F7F7F bit pattern, dmap <- 0. */
 int smx_dev_init_wta(float* d_best, float* d_dmap, int64_t n, void* stream);
+
+int smx_dev_filter(const smx_params* p, const uint8_t* d_image, int w, int h, uint8_t* d_mean,
+                   float* d_var, void* stream);
 
 int smx_dev_detect_occlusion(const smx_params* p, float* d_dL, const float* d_dR, int dOcclusion,
                              int w, int h, void* stream);
 int smx_dev_fill_occlusion(float* d_disp, int w, int h, float vMin, void* stream);
 
 /* Host-side helpers for the packed key (same encoding as the kernels). */
-uint64_t smx_pack_key(float cost, uint32_t slice);
-void smx_unpack_key(uint64_t key, float* cost, uint32_t* slice);
+int64_t smx_pack_key(float cost, uint32_t slice);
+void smx_unpack_key(int64_t key, float* cost, uint32_t* slice);
 
 /* Cumulative device time (ms) of the aggregation kernels launched by the most recent
  * smx_dev_aggregate_wta call on this thread when timing was enabled with

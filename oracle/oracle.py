@@ -10,11 +10,12 @@ _SO = os.path.join(_HERE, "_build", "libsmx_oracle.so")
 
 __all__ = [
     "build", "lib", "Params", "gray", "xderiv", "cost_volume", "integral", "box_mean",
-    "guidance", "init_wta", "guided_filter", "detect_occlusion", "fill_occlusion",
-    "write_mat_u8", "stereo_pair", "pack_keys", "unpack_keys", "WTA_INIT_BITS",
+    "guidance", "filter", "init_wta", "guided_filter", "detect_occlusion", "fill_occlusion",
+    "write_mat_u8", "stereo_pair", "pack_keys", "unpack_keys", "WTA_INIT_BITS", "KEY_IDENTITY",
 ]
 
 WTA_INIT_BITS = 0x7F7F7F7F  # main.cu:112 memset(best, 9999999.0f) -> bytes 0x7F
+KEY_IDENTITY = 0x7FFFFFFFFFFFFFFF  # packed-key identity (signed 64-bit order)
 
 
 class Params(C.Structure):
@@ -38,7 +39,7 @@ def lib():
     if _lib is None:
         build()
         _lib = C.CDLL(_SO)
-        _lib.orc_pack_key.restype = C.c_uint64
+        _lib.orc_pack_key.restype = C.c_int64
         _lib.orc_pack_key.argtypes = [C.c_float, C.c_uint32]
     return _lib
 
@@ -191,23 +192,34 @@ def stereo_pair(Il, Ir, size_d, dminl=None, dminr=0, want_cost=False, want_agg=F
     return r
 
 
+def filter(I, params=None):
+    """Dead `filter()` of the reference (filter.cu:117-207): (mean u8, var f32)."""
+    I = _u8(I)
+    h, w = I.shape
+    mean = np.empty((h, w), np.uint8)
+    var = np.empty((h, w), np.float32)
+    lib().orc_filter(C.byref(_params(params)), _p(I, C.c_uint8), _p(mean, C.c_uint8),
+                     _p(var, C.c_float), w, h)
+    return mean, var
+
+
 def pack_keys(best, slices):
     """numpy restatement of orc_pack_key over arrays (checked against the C one in tests)."""
     b = _f32(best).copy()
     b[b == 0.0] = 0.0
     u = b.view(np.uint32)
     neg = (u & np.uint32(0x80000000)) != 0
-    o = np.where(neg, ~u, u | np.uint32(0x80000000)).astype(np.uint64)
+    o = np.where(neg, ~u ^ np.uint32(0x80000000), u).astype(np.uint64)
     lo = (np.uint64(0xFFFFFFFF) - np.asarray(slices).astype(np.uint64))
-    keys = (o << np.uint64(32)) | lo
-    return np.where(np.isnan(b), np.uint64(0xFFFFFFFFFFFFFFFF), keys)
+    keys = ((o << np.uint64(32)) | lo).view(np.int64)
+    return np.where(np.isnan(b), np.int64(KEY_IDENTITY), keys)
 
 
 def unpack_keys(keys):
-    keys = np.asarray(keys, dtype=np.uint64)
+    keys = np.asarray(keys, dtype=np.int64).view(np.uint64)
     u = (keys >> np.uint64(32)).astype(np.uint32)
-    pos = (u & np.uint32(0x80000000)) != 0
-    bits = np.where(pos, u & np.uint32(0x7FFFFFFF), ~u).astype(np.uint32)
+    neg = (u & np.uint32(0x80000000)) != 0
+    bits = np.where(neg, ~(u ^ np.uint32(0x80000000)), u).astype(np.uint32)
     best = bits.view(np.float32)
     slices = (np.uint64(0xFFFFFFFF) - (keys & np.uint64(0xFFFFFFFF))).astype(np.int64)
     return best, slices

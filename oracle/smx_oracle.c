@@ -327,22 +327,54 @@ ORC_API void orc_stereo_pair(const orc_params* P, const uint8_t* Il, const uint8
     if (!costr_out) free(costr);
 }
 
-/* ---- packed WTA key (no reference counterpart; SURVEY.md 8e) --------------
- * key = (ord(best) << 32) | (0xFFFFFFFF - slice) ; min key == min cost and, on
- * equal cost, the LARGEST slice, i.e. the sequential `>=` rule of dispSelect.
- * ord: monotone f32 -> u32 map (-0 canonicalised to +0). */
-ORC_API uint64_t orc_pack_key(float best, uint32_t slice) {
-    uint32_t u;
-    if (best != best) return ~(uint64_t)0; /* NaN never wins (`best >= q` is false) */
-    if (best == 0.0f) best = 0.0f; /* -0 -> +0 */
-    memcpy(&u, &best, 4);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return ((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - slice);
+/* ---- filter.cu:117-207 (filter(): dead code in the reference) ---------------
+ * Direct zero-padded (2R+1)^2 box sums in f32, x offset outer / y offset inner
+ * (filter.cu:57-61), truncated means (:63-64), var = mean(I*I) - mean*mean with
+ * the u8 mean (:143-181). */
+ORC_API void orc_filter(const orc_params* P, const uint8_t* I, uint8_t* mean, float* var,
+                        int w, int h) {
+    const int R = P->radius;
+    const int area = (2 * R + 1) * (2 * R + 1);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float s1 = 0.0f, s2 = 0.0f;
+            for (int ix = -R; ix <= R; ++ix)
+                for (int iy = -R; iy <= R; ++iy) {
+                    int xx = x + ix, yy = y + iy;
+                    float v = 0.0f, v2 = 0.0f;
+                    if (xx >= 0 && xx < w && yy >= 0 && yy < h) {
+                        int c = (int)I[(int64_t)yy * w + xx];
+                        v = (float)c;
+                        v2 = (float)(c * c);
+                    }
+                    s1 += v;
+                    s2 += v2;
+                }
+            int m = (int)(s1 / area);
+            int m2 = (int)(s2 / area);
+            uint8_t mu = (uint8_t)m;
+            mean[(int64_t)y * w + x] = mu;
+            var[(int64_t)y * w + x] = (float)m2 - (float)((int)mu * (int)mu);
+        }
 }
 
-ORC_API void orc_unpack_key(uint64_t key, float* best, uint32_t* slice) {
-    uint32_t u = (uint32_t)(key >> 32);
-    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+/* ---- packed WTA key (no reference counterpart; SURVEY.md 8e) --------------
+ * key = (sord(best) << 32) | (0xFFFFFFFF - slice) compared as SIGNED 64-bit
+ * integers; min key == min cost and, on equal cost, the LARGEST slice, i.e. the
+ * sequential `>=` rule of dispSelect.  sord: order-preserving f32 -> i32 map
+ * (-0 canonicalised to +0).  Identity (and NaN, which never wins) = INT64_MAX. */
+ORC_API int64_t orc_pack_key(float best, uint32_t slice) {
+    uint32_t u;
+    if (best != best) return INT64_MAX; /* NaN never wins (`best >= q` is false) */
+    if (best == 0.0f) best = 0.0f; /* -0 -> +0 */
+    memcpy(&u, &best, 4);
+    if (u & 0x80000000u) u = ~u ^ 0x80000000u; /* negative floats: reverse their order */
+    return (int64_t)(((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - slice));
+}
+
+ORC_API void orc_unpack_key(int64_t key, float* best, uint32_t* slice) {
+    uint32_t u = (uint32_t)((uint64_t)key >> 32);
+    if (u & 0x80000000u) u = ~(u ^ 0x80000000u);
     memcpy(best, &u, 4);
-    *slice = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
+    *slice = 0xFFFFFFFFu - (uint32_t)((uint64_t)key & 0xFFFFFFFFu);
 }

@@ -15,8 +15,8 @@ loudly if it has not been built.
 """
 from ._lib import Params, SmxError, build, check, default_params, lib  # noqa: F401
 from .stages import (compute_cost, compute_guided_filter, detect_occlusion,  # noqa: F401
-                     fill_occlusion, init_wta, integral, rgb_to_grayscale, stereo_pair, write_mat)
+                     fill_occlusion, filter, init_wta, integral, rgb_to_grayscale, stereo_pair, write_mat)
 
 __all__ = ["Params", "SmxError", "build", "default_params", "lib", "rgb_to_grayscale",
            "compute_cost", "compute_guided_filter", "integral", "detect_occlusion", "fill_occlusion",
-           "init_wta", "stereo_pair", "write_mat"]
+           "init_wta", "stereo_pair", "write_mat", "filter", "check"]

@@ -56,6 +56,8 @@ SIGNATURES = {
     "smx_compute_guided_filter": (_i, [_PP, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i]),
     "smx_detect_occlusion": (_i, [_PP, _vp, _vp, _i, _i, _i]),
     "smx_fill_occlusion": (_i, [_vp, _i, _i, _f]),
+    "smx_filter": (_i, [_PP, _vp, _i, _i, _vp, _vp]),
+    "smx_dev_filter": (_i, [_PP, _vp, _i, _i, _vp, _vp, _vp]),
     "smx_stereo_pair": (_i, [_PP, _vp, _vp, _i, _i, _i, _i, _i, C.POINTER(PairOut)]),
     "smx_dev_rgb_to_grayscale": (_i, [_PP, _vp, _i64, _i, _vp, _vp]),
     "smx_dev_cost_volume": (_i, [_PP, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
@@ -69,8 +71,8 @@ SIGNATURES = {
     "smx_dev_init_wta": (_i, [_vp, _vp, _i64, _vp]),
     "smx_dev_detect_occlusion": (_i, [_PP, _vp, _vp, _i, _i, _i, _vp]),
     "smx_dev_fill_occlusion": (_i, [_vp, _i, _i, _f, _vp]),
-    "smx_pack_key": (_u64, [_f, _u32]),
-    "smx_unpack_key": (None, [_u64, C.POINTER(_f), C.POINTER(_u32)]),
+    "smx_pack_key": (_i64, [_f, _u32]),
+    "smx_unpack_key": (None, [_i64, C.POINTER(_f), C.POINTER(_u32)]),
     "smx_set_agg_path": (_i, [_i]),
     "smx_last_agg_path": (_i, []),
     "smx_agg_geometry": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),

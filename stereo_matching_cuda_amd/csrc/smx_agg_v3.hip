@@ -773,15 +773,15 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
 // ---------------------------------------------------------------------------------------------
 struct WtaArgs {
     const float* q[2];
-    uint64_t* keys[2];
+    int64_t* keys[2];
 };
 
 __global__ __launch_bounds__(256) void k_v3_wta(WtaArgs wa, size_t n, int count, int slice0) {
     const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (id >= n) return;
     const float* __restrict__ q = wa.q[blockIdx.y] + id;
-    uint64_t* keys = wa.keys[blockIdx.y];
-    uint64_t key = keys[id];
+    int64_t* keys = wa.keys[blockIdx.y];
+    int64_t key = keys[id];
     int z = 0;
     for (; z + 8 <= count; z += 8) {
         float v[8];
@@ -789,12 +789,12 @@ __global__ __launch_bounds__(256) void k_v3_wta(WtaArgs wa, size_t n, int count,
         for (int t = 0; t < 8; ++t) v[t] = __builtin_nontemporal_load(&q[(size_t)(z + t) * n]);
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            uint64_t kk = pack_key(v[t], (uint32_t)(slice0 + z + t));
+            int64_t kk = pack_key(v[t], (uint32_t)(slice0 + z + t));
             key = kk < key ? kk : key;
         }
     }
     for (; z < count; ++z) {
-        uint64_t kk = pack_key(__builtin_nontemporal_load(&q[(size_t)z * n]), (uint32_t)(slice0 + z));
+        int64_t kk = pack_key(__builtin_nontemporal_load(&q[(size_t)z * n]), (uint32_t)(slice0 + z));
         key = kk < key ? kk : key;
     }
     keys[id] = key;
@@ -879,7 +879,7 @@ int v3_read_status(const void* d_ws, unsigned* out) {
 
 int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                  const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
-                 const int* dmin, int s_begin, int s_end, uint64_t* const* d_keys,
+                 const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
                  uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
                  hipStream_t st, int* launches) {
     const int R = p->radius;

@@ -22,7 +22,7 @@ bool v3_supported(const smx_params* p);
 size_t v3_workspace_bytes(int w, int h, int nslices);
 int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                  const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
-                 const int* dmin, int s_begin, int s_end, uint64_t* const* d_keys,
+                 const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
                  uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
                  hipStream_t st, int* launches);
 
@@ -74,8 +74,8 @@ int smx_device_count(void) {
     return n;
 }
 
-uint64_t smx_pack_key(float cost, uint32_t slice) { return pack_key(cost, slice); }
-void smx_unpack_key(uint64_t key, float* cost, uint32_t* slice) {
+int64_t smx_pack_key(float cost, uint32_t slice) { return pack_key(cost, slice); }
+void smx_unpack_key(int64_t key, float* cost, uint32_t* slice) {
     float c; uint32_t s;
     unpack_key(key, &c, &s);
     if (cost) *cost = c;
@@ -161,7 +161,23 @@ int smx_dev_agg_status(const void* d_workspace) {
     return SMX_OK;
 }
 
-int smx_dev_init_keys(uint64_t* d_keys, int64_t n, void* stream) {
+// The kernels are launched on the CURRENT device: a workspace that lives on another one is a caller bug
+// that would otherwise fault on the GPU.
+static int check_same_device(const void* d_ws, const char* who) {
+    hipPointerAttribute_t a;
+    int dev = -1;
+    if (hipPointerGetAttributes(&a, d_ws) != hipSuccess) {
+        (void)hipGetLastError();
+        return SMX_OK;   // not a pointer the runtime knows (e.g. a sub-allocation it cannot resolve): let it through
+    }
+    SMX_HIP(hipGetDevice(&dev));
+    if (a.type == hipMemoryTypeDevice && a.device != dev)
+        return fail(SMX_E_ARG, "%s: workspace lives on device %d but the current device is %d "
+                               "(hipSetDevice to the workspace's device before the call)", who, a.device, dev);
+    return SMX_OK;
+}
+
+int smx_dev_init_keys(int64_t* d_keys, int64_t n, void* stream) {
     SMX_ARG(d_keys && n > 0);
     return launch_init_keys(d_keys, n, (hipStream_t)stream);
 }
@@ -171,7 +187,7 @@ int smx_dev_init_wta(float* d_best, float* d_dmap, int64_t n, void* stream) {
     return launch_init_wta(d_best, d_dmap, n, (hipStream_t)stream);
 }
 
-int smx_dev_apply_keys(const uint64_t* d_keys, int64_t n, int dmin, float* d_best, float* d_dmap,
+int smx_dev_apply_keys(const int64_t* d_keys, int64_t n, int dmin, float* d_best, float* d_dmap,
                        void* stream) {
     SMX_ARG(d_keys && d_best && d_dmap && n > 0);
     return launch_apply_keys(d_keys, n, dmin, d_best, d_dmap, (hipStream_t)stream);
@@ -190,11 +206,12 @@ int smx_dev_fill_occlusion(float* d_disp, int w, int h, float vMin, void* stream
 
 int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uint8_t* d_other,
                           const float* d_cost, int w, int h, int dmin, int s_begin, int s_end,
-                          uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
+                          int64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
                           size_t workspace_bytes, void* stream) {
     SMX_ARG(p && d_guide && d_keys && d_workspace);
     SMX_ARG(d_cost || d_other);
     SMX_ARG(w >= 2 && h >= 1 && s_begin >= 0 && s_end >= s_begin && p->radius >= 0);
+    { int rcd = check_same_device(d_workspace, "smx_dev_aggregate_wta"); if (rcd) return rcd; }
     hipStream_t st = (hipStream_t)stream;
     // fused path (smx_agg_v3.hip): radius <= 9; cost built on the fly or read from d_cost
     const bool can_v3 = v3_supported(p);
@@ -281,10 +298,11 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
 
 int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const uint8_t* d_right,
                                int w, int h, int dminl, int dminr, int s_begin, int s_end,
-                               uint64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
+                               int64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
                                size_t workspace_bytes, void* stream) {
     SMX_ARG(p && d_left && d_right && d_keys && d_workspace);
     SMX_ARG(w >= 2 && h >= 1 && s_begin >= 0 && s_end >= s_begin && p->radius >= 0);
+    { int rcd = check_same_device(d_workspace, "smx_dev_aggregate_wta_pair"); if (rcd) return rcd; }
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)w * h;
     const int64_t vol = n * (s_end - s_begin);
@@ -292,7 +310,7 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
         const uint8_t* guide[2] = {d_left, d_right};
         const uint8_t* other[2] = {d_right, d_left};
         const int dmin[2] = {dminl, dminr};
-        uint64_t* keys[2] = {d_keys, d_keys + n};
+        int64_t* keys[2] = {d_keys, d_keys + n};
         uint8_t* mean[2] = {d_mean_u8, d_mean_u8 ? d_mean_u8 + n : nullptr};
         float* agg[2] = {d_agg, d_agg ? d_agg + vol : nullptr};
         g_launches = 0;
@@ -389,7 +407,7 @@ int smx_compute_guided_filter(const smx_params* p, const uint8_t* i, const float
     SMX_HIP(dBest.alloc(n * sizeof(float)));
     SMX_HIP(dMap.alloc(n * sizeof(float)));
     SMX_HIP(dMean.alloc(n));
-    SMX_HIP(dKeys.alloc(n * sizeof(uint64_t)));
+    SMX_HIP(dKeys.alloc(n * sizeof(int64_t)));
     if (agg) SMX_HIP(dAgg.alloc(n * size_d * sizeof(float)));
     SMX_HIP(ws.alloc(ws_bytes));
     SMX_HIP(hipMemcpy(dI.p, i, n, hipMemcpyHostToDevice));
@@ -397,15 +415,16 @@ int smx_compute_guided_filter(const smx_params* p, const uint8_t* i, const float
     SMX_HIP(hipMemcpy(dBest.p, filter_cost, n * sizeof(float), hipMemcpyHostToDevice));
     SMX_HIP(hipMemcpy(dMap.p, disp_map, n * sizeof(float), hipMemcpyHostToDevice));
     int rc;
-    if ((rc = smx_dev_init_keys(dKeys.as<uint64_t>(), (int64_t)n, nullptr))) return rc;
+    if ((rc = smx_dev_init_keys(dKeys.as<int64_t>(), (int64_t)n, nullptr))) return rc;
     if ((rc = smx_dev_aggregate_wta(p, dI.as<uint8_t>(), nullptr, dC.as<float>(), w, h, dmin, 0,
-                                    size_d, dKeys.as<uint64_t>(), dMean.as<uint8_t>(),
+                                    size_d, dKeys.as<int64_t>(), dMean.as<uint8_t>(),
                                     agg ? dAgg.as<float>() : nullptr, ws.p, ws_bytes, nullptr)))
         return rc;
-    if ((rc = smx_dev_apply_keys(dKeys.as<uint64_t>(), (int64_t)n, dmin, dBest.as<float>(),
+    if ((rc = smx_dev_apply_keys(dKeys.as<int64_t>(), (int64_t)n, dmin, dBest.as<float>(),
                                  dMap.as<float>(), nullptr)))
         return rc;
     SMX_HIP(hipDeviceSynchronize());
+    if ((rc = smx_dev_agg_status(ws.p))) return rc;
     SMX_HIP(hipMemcpy(filter_cost, dBest.p, n * sizeof(float), hipMemcpyDeviceToHost));
     SMX_HIP(hipMemcpy(disp_map, dMap.p, n * sizeof(float), hipMemcpyDeviceToHost));
     if (mean) SMX_HIP(hipMemcpy(mean, dMean.p, n, hipMemcpyDeviceToHost));
@@ -442,69 +461,110 @@ int smx_fill_occlusion(float* disparity, int w, int h, float vMin) {
     return SMX_OK;
 }
 
+int smx_dev_filter(const smx_params* p, const uint8_t* d_image, int w, int h, uint8_t* d_mean,
+                   float* d_var, void* stream) {
+    SMX_ARG(p && d_image && d_mean && d_var && w >= 1 && h >= 1 && p->radius >= 0);
+    return launch_filter(p, d_image, d_mean, d_var, w, h, (hipStream_t)stream);
+}
+
+int smx_filter(const smx_params* p, const uint8_t* image, int w, int h, uint8_t* mean, float* var) {
+    SMX_ARG(p && image && mean && var && w >= 1 && h >= 1 && p->radius >= 0);
+    const size_t n = (size_t)w * h;
+    DevBuf dI, dM, dV;
+    SMX_HIP(dI.alloc(n));
+    SMX_HIP(dM.alloc(n));
+    SMX_HIP(dV.alloc(n * sizeof(float)));
+    SMX_HIP(hipMemcpy(dI.p, image, n, hipMemcpyHostToDevice));
+    int rc = smx_dev_filter(p, dI.as<uint8_t>(), w, h, dM.as<uint8_t>(), dV.as<float>(), nullptr);
+    if (rc) return rc;
+    SMX_HIP(hipDeviceSynchronize());
+    SMX_HIP(hipMemcpy(mean, dM.p, n, hipMemcpyDeviceToHost));
+    SMX_HIP(hipMemcpy(var, dV.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
 int smx_stereo_pair(const smx_params* p, const uint8_t* gray_l, const uint8_t* gray_r, int w, int h,
                     int size_d, int dminl, int dminr, const smx_pair_out* out) {
     SMX_ARG(p && gray_l && gray_r && out && w >= 2 && h >= 1 && size_d >= 1);
     const size_t n = (size_t)w * h;
     const size_t fb = n * sizeof(float);
     const size_t vb = fb * size_d;
-    const size_t ws_bytes = pick_ws_bytes(w, h, size_d);
-    DevBuf dL, dR, keysL, keysR, bestL, bestR, mapL, mapR, meanL, meanR, occ, fil, ws;
-    DevBuf costL, costR, aggL, aggR;
+    const size_t ws_bytes = 2 * pick_ws_bytes(w, h, size_d);     // both views per launch
+    // keys / best / dmap / mean: left view first, right view behind it (one buffer each)
+    DevBuf dL, dR, keys, best, map, mean, occ, fil, ws;
+    DevBuf costL, costR, aggLR;
     SMX_HIP(dL.alloc(n)); SMX_HIP(dR.alloc(n));
-    SMX_HIP(keysL.alloc(n * 8)); SMX_HIP(keysR.alloc(n * 8));
-    SMX_HIP(bestL.alloc(fb)); SMX_HIP(bestR.alloc(fb));
-    SMX_HIP(mapL.alloc(fb)); SMX_HIP(mapR.alloc(fb));
-    SMX_HIP(meanL.alloc(n)); SMX_HIP(meanR.alloc(n));
+    SMX_HIP(keys.alloc(2 * n * 8));
+    SMX_HIP(best.alloc(2 * fb)); SMX_HIP(map.alloc(2 * fb));
+    SMX_HIP(mean.alloc(2 * n));
     SMX_HIP(occ.alloc(fb)); SMX_HIP(fil.alloc(fb));
     SMX_HIP(ws.alloc(ws_bytes));
-    if (out->cost_l) SMX_HIP(costL.alloc(vb));
-    if (out->cost_r) SMX_HIP(costR.alloc(vb));
-    if (out->agg_l) SMX_HIP(aggL.alloc(vb));
-    if (out->agg_r) SMX_HIP(aggR.alloc(vb));
+    const bool want_cost = out->cost_l || out->cost_r;
+    const bool want_agg = out->agg_l || out->agg_r;
+    if (want_cost) { SMX_HIP(costL.alloc(vb)); SMX_HIP(costR.alloc(vb)); }
+    if (want_agg) SMX_HIP(aggLR.alloc(2 * vb));
     SMX_HIP(hipMemcpy(dL.p, gray_l, n, hipMemcpyHostToDevice));
     SMX_HIP(hipMemcpy(dR.p, gray_r, n, hipMemcpyHostToDevice));
     int rc;
     const int64_t nn = (int64_t)n;
-    // cost volumes are materialised only when the caller asks for them (main.cu:80-82);
-    // otherwise the slices are built on the fly inside the aggregation.
-    if (out->cost_l && (rc = smx_dev_cost_volume(p, dL.as<uint8_t>(), dR.as<uint8_t>(),
-                                                 costL.as<float>(), w, w, h, dminl, 0, size_d, nullptr)))
-        return rc;
-    if (out->cost_r && (rc = smx_dev_cost_volume(p, dR.as<uint8_t>(), dL.as<uint8_t>(),
-                                                 costR.as<float>(), w, w, h, dminr, 0, size_d, nullptr)))
-        return rc;
-    if ((rc = smx_dev_init_keys(keysL.as<uint64_t>(), nn, nullptr))) return rc;
-    if ((rc = smx_dev_init_keys(keysR.as<uint64_t>(), nn, nullptr))) return rc;
-    if ((rc = smx_dev_init_wta(bestL.as<float>(), mapL.as<float>(), nn, nullptr))) return rc;
-    if ((rc = smx_dev_init_wta(bestR.as<float>(), mapR.as<float>(), nn, nullptr))) return rc;
-    // main.cu:133-134
-    if ((rc = smx_dev_aggregate_wta(p, dL.as<uint8_t>(), dR.as<uint8_t>(),
-                                    out->cost_l ? costL.as<float>() : nullptr, w, h, dminl, 0, size_d,
-                                    keysL.as<uint64_t>(), meanL.as<uint8_t>(),
-                                    out->agg_l ? aggL.as<float>() : nullptr, ws.p, ws_bytes, nullptr)))
-        return rc;
-    if ((rc = smx_dev_aggregate_wta(p, dR.as<uint8_t>(), dL.as<uint8_t>(),
-                                    out->cost_r ? costR.as<float>() : nullptr, w, h, dminr, 0, size_d,
-                                    keysR.as<uint64_t>(), meanR.as<uint8_t>(),
-                                    out->agg_r ? aggR.as<float>() : nullptr, ws.p, ws_bytes, nullptr)))
-        return rc;
-    if ((rc = smx_dev_apply_keys(keysL.as<uint64_t>(), nn, dminl, bestL.as<float>(), mapL.as<float>(), nullptr))) return rc;
-    if ((rc = smx_dev_apply_keys(keysR.as<uint64_t>(), nn, dminr, bestR.as<float>(), mapR.as<float>(), nullptr))) return rc;
+    float* bestL = best.as<float>(); float* bestR = bestL + n;
+    float* mapL = map.as<float>();   float* mapR = mapL + n;
+    int64_t* keysL = keys.as<int64_t>(); int64_t* keysR = keysL + n;
+    // cost volumes are materialised only when the caller asks for them (main.cu:80-82) and then feed
+    // the aggregation like in the reference; otherwise the slices are built on the fly inside it.
+    if (want_cost) {
+        if ((rc = smx_dev_cost_volume(p, dL.as<uint8_t>(), dR.as<uint8_t>(), costL.as<float>(), w, w, h,
+                                      dminl, 0, size_d, nullptr))) return rc;
+        if ((rc = smx_dev_cost_volume(p, dR.as<uint8_t>(), dL.as<uint8_t>(), costR.as<float>(), w, w, h,
+                                      dminr, 0, size_d, nullptr))) return rc;
+    }
+    if ((rc = smx_dev_init_keys(keysL, 2 * nn, nullptr))) return rc;
+    if ((rc = smx_dev_init_wta(bestL, mapL, 2 * nn, nullptr))) return rc;
+    // main.cu:133-134, both views per kernel launch
+    if (v3_supported(p) && g_agg_path != 1) {
+        const uint8_t* guide[2] = {dL.as<uint8_t>(), dR.as<uint8_t>()};
+        const uint8_t* other[2] = {dR.as<uint8_t>(), dL.as<uint8_t>()};
+        const float* cost[2] = {costL.as<float>(), costR.as<float>()};
+        const int dmin[2] = {dminl, dminr};
+        int64_t* kv[2] = {keysL, keysR};
+        uint8_t* mv[2] = {mean.as<uint8_t>(), mean.as<uint8_t>() + n};
+        float* av[2] = {aggLR.as<float>(), want_agg ? aggLR.as<float>() + (size_t)size_d * n : nullptr};
+        g_launches = 0;
+        if ((rc = aggregate_v3(p, 2, guide, other, want_cost ? cost : nullptr, w, h, dmin, 0, size_d, kv, mv,
+                               want_agg ? av : nullptr, ws.p, ws_bytes, nullptr, &g_launches)))
+            return rc;
+        g_last_path = 2;
+    } else {
+        if ((rc = smx_dev_aggregate_wta(p, dL.as<uint8_t>(), dR.as<uint8_t>(),
+                                        want_cost ? costL.as<float>() : nullptr, w, h, dminl, 0, size_d, keysL,
+                                        mean.as<uint8_t>(), want_agg ? aggLR.as<float>() : nullptr, ws.p,
+                                        ws_bytes, nullptr)))
+            return rc;
+        if ((rc = smx_dev_aggregate_wta(p, dR.as<uint8_t>(), dL.as<uint8_t>(),
+                                        want_cost ? costR.as<float>() : nullptr, w, h, dminr, 0, size_d, keysR,
+                                        mean.as<uint8_t>() + n,
+                                        want_agg ? aggLR.as<float>() + (size_t)size_d * n : nullptr, ws.p,
+                                        ws_bytes, nullptr)))
+            return rc;
+    }
+    if ((rc = smx_dev_apply_keys(keysL, nn, dminl, bestL, mapL, nullptr))) return rc;
+    if ((rc = smx_dev_apply_keys(keysR, nn, dminr, bestR, mapR, nullptr))) return rc;
     // main.cu:140-155
-    SMX_HIP(hipMemcpyAsync(occ.p, mapL.p, fb, hipMemcpyDeviceToDevice, nullptr));
-    if ((rc = smx_dev_detect_occlusion(p, occ.as<float>(), mapR.as<float>(), dminl - 100, w, h, nullptr))) return rc;
+    SMX_HIP(hipMemcpyAsync(occ.p, mapL, fb, hipMemcpyDeviceToDevice, nullptr));
+    if ((rc = smx_dev_detect_occlusion(p, occ.as<float>(), mapR, dminl - 100, w, h, nullptr))) return rc;
     SMX_HIP(hipMemcpyAsync(fil.p, occ.p, fb, hipMemcpyDeviceToDevice, nullptr));
     if ((rc = smx_dev_fill_occlusion(fil.as<float>(), w, h, (float)dminl, nullptr))) return rc;
     SMX_HIP(hipDeviceSynchronize());
-    struct { void* dst; void* src; size_t b; } copies[] = {
-        {out->best_l, bestL.p, fb}, {out->best_r, bestR.p, fb}, {out->dmap_l, mapL.p, fb},
-        {out->dmap_r, mapR.p, fb},  {out->mean_l, meanL.p, n},  {out->mean_r, meanR.p, n},
+    if ((rc = smx_dev_agg_status(ws.p))) return rc;
+    struct { void* dst; const void* src; size_t b; } copies[] = {
+        {out->best_l, bestL, fb}, {out->best_r, bestR, fb}, {out->dmap_l, mapL, fb},
+        {out->dmap_r, mapR, fb},  {out->mean_l, mean.p, n}, {out->mean_r, mean.as<uint8_t>() + n, n},
         {out->occlusion, occ.p, fb}, {out->filled, fil.p, fb},  {out->cost_l, costL.p, vb},
-        {out->cost_r, costR.p, vb}, {out->agg_l, aggL.p, vb},   {out->agg_r, aggR.p, vb},
+        {out->cost_r, costR.p, vb}, {out->agg_l, aggLR.p, vb},
+        {out->agg_r, want_agg ? (const void*)(aggLR.as<float>() + (size_t)size_d * n) : nullptr, vb},
     };
     for (auto& c : copies)
-        if (c.dst) SMX_HIP(hipMemcpy(c.dst, c.src, c.b, hipMemcpyDeviceToHost));
+        if (c.dst && c.src) SMX_HIP(hipMemcpy(c.dst, c.src, c.b, hipMemcpyDeviceToHost));
     return SMX_OK;
 }
 

@@ -49,22 +49,26 @@ inline CostConst make_cost_const(const smx_params* p) {
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- packed WTA key ---------------------------------------------------------------------
-// key = ord(cost) << 32 | (0xFFFFFFFF - slice); ord = monotone f32 -> u32 (-0 folded to +0).
+// key = sord(cost) << 32 | (0xFFFFFFFF - slice), compared as SIGNED 64-bit integers: sord = monotone
+// f32 -> i32 (-0 folded to +0), so that the per-pixel reduction of the shards is a plain int64 MIN
+// (RCCL ncclInt64 / torch.int64) with no re-encoding.  Smallest key = smallest cost, and among equal
+// costs the LARGEST slice: the reference's `best >= q` rule with ascending slices.
 // A NaN cost (only from degenerate parameters, e.g. var + eps == 0) never wins, like the reference's
-// `best >= q`, which is false for NaN: it maps to the identity key.
-__host__ __device__ inline uint64_t pack_key(float cost, uint32_t slice) {
-    if (cost != cost) return ~0ull;
+// `best >= q`, which is false for NaN: it maps to the identity key INT64_MAX.
+constexpr int64_t KEY_IDENTITY = 0x7FFFFFFFFFFFFFFFll;
+__host__ __device__ inline int64_t pack_key(float cost, uint32_t slice) {
+    if (cost != cost) return KEY_IDENTITY;
     if (cost == 0.0f) cost = 0.0f;
     uint32_t u = __builtin_bit_cast(uint32_t, cost);
-    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return ((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - slice);
+    u = (u & 0x80000000u) ? (~u ^ 0x80000000u) : u;      // negative floats: reverse their order
+    return (int64_t)(((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - slice));
 }
 
-__host__ __device__ inline void unpack_key(uint64_t key, float* cost, uint32_t* slice) {
-    uint32_t u = (uint32_t)(key >> 32);
-    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;
+__host__ __device__ inline void unpack_key(int64_t key, float* cost, uint32_t* slice) {
+    uint32_t u = (uint32_t)((uint64_t)key >> 32);
+    u = (u & 0x80000000u) ? ~(u ^ 0x80000000u) : u;
     *cost = __builtin_bit_cast(float, u);
-    *slice = 0xFFFFFFFFu - (uint32_t)(key & 0xFFFFFFFFu);
+    *slice = 0xFFFFFFFFu - (uint32_t)((uint64_t)key & 0xFFFFFFFFu);
 }
 
 }  // namespace smx

@@ -267,7 +267,7 @@ __global__ void k_ab(const float* __restrict__ Sp, const float* __restrict__ SIp
 // min reproduces `if (best >= q) {...}` with slices ascending: ties go to the larger slice.
 // =====================================================================================
 __global__ void k_q_wta(const float* __restrict__ Sa, const float* __restrict__ Sb,
-                        const float* __restrict__ im, uint64_t* __restrict__ keys,
+                        const float* __restrict__ im, int64_t* __restrict__ keys,
                         float* __restrict__ agg, int w, int h, int count, int slice0, int R) {
     int x = blockIdx.x * blockDim.x + threadIdx.x;
     int y = blockIdx.y;
@@ -276,23 +276,23 @@ __global__ void k_q_wta(const float* __restrict__ Sa, const float* __restrict__ 
     BoxTaps t = box_taps(x, y, w, h, R);
     int64_t id = (int64_t)y * w + x;
     float I = im[id];
-    uint64_t key = keys[id];
+    int64_t key = keys[id];
     for (int z = 0; z < count; ++z) {
         const int64_t po = (int64_t)z * n;
         float abar = box_eval(Sa + po, t);
         float bbar = box_eval(Sb + po, t);
         float m = abar * I;
         float q = m + bbar;
-        uint64_t k = pack_key(q, (uint32_t)(slice0 + z));
+        int64_t k = pack_key(q, (uint32_t)(slice0 + z));
         key = k < key ? k : key;
         if (agg) agg[po + id] = q;
     }
     keys[id] = key;
 }
 
-__global__ void k_init_keys(uint64_t* keys, int64_t n) {
+__global__ void k_init_keys(int64_t* keys, int64_t n) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) keys[k] = ~0ull;
+    if (k < n) keys[k] = KEY_IDENTITY;
 }
 
 __global__ void k_init_wta(float* best, float* dmap, int64_t n) {
@@ -304,12 +304,12 @@ __global__ void k_init_wta(float* best, float* dmap, int64_t n) {
 }
 
 // dispSelectOnGPU (guidedFilter.cu:403-411) applied once to the winning slice of the key.
-__global__ void k_apply_keys(const uint64_t* __restrict__ keys, int64_t n, int dmin, float* best,
+__global__ void k_apply_keys(const int64_t* __restrict__ keys, int64_t n, int dmin, float* best,
                              float* dmap) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    uint64_t key = keys[k];
-    if (key == ~0ull) return;
+    int64_t key = keys[k];
+    if (key == KEY_IDENTITY) return;
     float q;
     uint32_t s;
     unpack_key(key, &q, &s);
@@ -375,6 +375,44 @@ __global__ __launch_bounds__(64) void k_fill_occlusion(float* disp, int w, int h
         float nv = __shfl(v, first);
         if (mask) carry = nv;
     }
+}
+
+// =====================================================================================
+// filter()  (filter.cu:117-207; dead code in the reference: never called from main.cu)
+// Direct (2R+1)^2 box filter with zero padding, f32 accumulation in the reference's order (x offset
+// outer, y offset inner, filter.cu:57-61), mean truncated to an integer:
+//   mean   = (uchar)(int)(sum(I) / (2R+1)^2)                       boxFilterOnGPU      :39-65
+//   var    = (float)(int)(sum(I*I) / (2R+1)^2) - (float)(mean*mean) multIm, boxFilterfloatOnGpu, sousIm
+// One thread per pixel; the 19 x 19 window comes from the L1/L2-resident u8 image (not a hot path).
+// =====================================================================================
+__global__ void k_filter(const uint8_t* __restrict__ I, uint8_t* __restrict__ mean,
+                         float* __restrict__ var, int w, int h, int R) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= w) return;
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int ix = -R; ix <= R; ++ix) {
+        const int xx = x + ix;
+        for (int iy = -R; iy <= R; ++iy) {
+            const int yy = y + iy;
+            float v = 0.0f, v2 = 0.0f;
+            if (xx >= 0 && xx < w && yy >= 0 && yy < h) {
+                const int c = (int)I[(int64_t)yy * w + xx];
+                v = (float)c;
+                v2 = (float)(c * c);      // multIm: u8 * u8 in int, then float
+            }
+            s1 += v;
+            s2 += v2;
+        }
+    }
+    const int area = (2 * R + 1) * (2 * R + 1);
+    const int m = (int)(s1 / area);
+    const int m2 = (int)(s2 / area);
+    const uint8_t mu = (uint8_t)m;
+    const int64_t id = (int64_t)y * w + x;
+    mean[id] = mu;
+    const float mm = (float)((int)mu * (int)mu);   // multIm(d_mean, d_mean)
+    var[id] = (float)m2 - mm;                     // sousIm
 }
 
 }  // namespace smx
@@ -449,7 +487,7 @@ int launch_ab(const smx_params* p, const float* Sp, const float* SIp, const floa
 }
 
 int launch_q_wta(const smx_params* p, const float* Sa, const float* Sb, const float* im,
-                 uint64_t* keys, float* agg, int w, int h, int count, int slice0, hipStream_t st) {
+                 int64_t* keys, float* agg, int w, int h, int count, int slice0, hipStream_t st) {
     if (count <= 0) return SMX_OK;
     dim3 grid(cdiv(w, 256), h);
     hipLaunchKernelGGL(k_q_wta, grid, dim3(256), 0, st, Sa, Sb, im, keys, agg, w, h, count, slice0,
@@ -458,7 +496,7 @@ int launch_q_wta(const smx_params* p, const float* Sa, const float* Sb, const fl
     return SMX_OK;
 }
 
-int launch_init_keys(uint64_t* keys, int64_t n, hipStream_t st) {
+int launch_init_keys(int64_t* keys, int64_t n, hipStream_t st) {
     hipLaunchKernelGGL(k_init_keys, dim3(cdiv(n, 256)), dim3(256), 0, st, keys, n);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
@@ -470,7 +508,7 @@ int launch_init_wta(float* best, float* dmap, int64_t n, hipStream_t st) {
     return SMX_OK;
 }
 
-int launch_apply_keys(const uint64_t* keys, int64_t n, int dmin, float* best, float* dmap,
+int launch_apply_keys(const int64_t* keys, int64_t n, int dmin, float* best, float* dmap,
                       hipStream_t st) {
     hipLaunchKernelGGL(k_apply_keys, dim3(cdiv(n, 256)), dim3(256), 0, st, keys, n, dmin, best,
                        dmap);
@@ -482,6 +520,13 @@ int launch_detect_occlusion(const smx_params* p, float* dL, const float* dR, int
                             hipStream_t st) {
     dim3 grid(cdiv(w, 256), h);
     hipLaunchKernelGGL(k_detect_occlusion, grid, dim3(256), 0, st, dL, dR, dOcc, w, h, p->d_lr);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+int launch_filter(const smx_params* p, const uint8_t* I, uint8_t* mean, float* var, int w, int h,
+                  hipStream_t st) {
+    hipLaunchKernelGGL(k_filter, dim3(cdiv(w, 256), h), dim3(256), 0, st, I, mean, var, w, h, p->radius);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

@@ -14,11 +14,13 @@ int launch_guid_finish(const smx_params* p, const float* S_im, const float* S_sq
 int launch_ab(const smx_params* p, const float* Sp, const float* SIp, const float* mean_im,
               const float* cinv, float* A, float* B, int w, int h, int nplanes, hipStream_t st);
 int launch_q_wta(const smx_params* p, const float* Sa, const float* Sb, const float* im,
-                 uint64_t* keys, float* agg, int w, int h, int count, int slice0, hipStream_t st);
-int launch_init_keys(uint64_t* keys, int64_t n, hipStream_t st);
+                 int64_t* keys, float* agg, int w, int h, int count, int slice0, hipStream_t st);
+int launch_init_keys(int64_t* keys, int64_t n, hipStream_t st);
 int launch_init_wta(float* best, float* dmap, int64_t n, hipStream_t st);
-int launch_apply_keys(const uint64_t* keys, int64_t n, int dmin, float* best, float* dmap, hipStream_t st);
+int launch_apply_keys(const int64_t* keys, int64_t n, int dmin, float* best, float* dmap, hipStream_t st);
 int launch_detect_occlusion(const smx_params* p, float* dL, const float* dR, int dOcc, int w, int h,
                             hipStream_t st);
 int launch_fill_occlusion(float* disp, int w, int h, float vMin, hipStream_t st);
+int launch_filter(const smx_params* p, const uint8_t* I, uint8_t* mean, float* var, int w, int h,
+                  hipStream_t st);
 }  // namespace smx

@@ -10,12 +10,6 @@ import torch
 
 from . import _lib
 
-_I64_MIN = -(1 << 63)
-
-
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
 
 def _dp(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
@@ -24,8 +18,10 @@ def _dp(t):
 class PairPipeline:
     """main.cu:65-155 for one stereo pair, optionally restricted to slices [s_begin, s_end) of
     both volumes (the D-shard of this rank).  Layout in HBM: gray images u8 [h][w]; per view packed
-    WTA keys u64 [h][w]; best/dmap/occlusion/filled f32 [h][w]; workspace = 5 guidance planes +
-    5 volumes of `slices_in_flight` slices (see smx_agg_workspace_bytes)."""
+    WTA keys i64 [h][w]; best/dmap/occlusion/filled f32 [h][w]; workspace = image / guidance planes +
+    per slice in flight one aggregated plane and the strip hand-off records (smx_agg_workspace_bytes).
+    Every launch goes to the pipeline's own device (torch.cuda.device(self.device)) on that device's
+    current stream, whatever device is current in the calling thread."""
 
     def __init__(self, w, h, size_d, dminl=None, dminr=0, s_begin=0, s_end=None, device="cuda:0",
                  slices_in_flight=None, want_agg=False, params=None, max_ws_bytes=64 << 30):
@@ -57,6 +53,12 @@ class PairPipeline:
         self.filled = torch.empty((self.h, self.w), **f)
         self.agg = (torch.empty((2, local, self.h, self.w), **f) if want_agg else None)
 
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _on_device(self):
+        return torch.cuda.device(self.device)
+
     # -- stages ------------------------------------------------------------------------------
     def aggregate(self, gray_l, gray_r, cost_l=None, cost_r=None):
         """Cost build (fused unless cost_* given) + guided-filter aggregation + running WTA of this
@@ -70,54 +72,49 @@ class PairPipeline:
 
     def aggregate_pair(self, gray_l, gray_r):
         """Both views per kernel launch (smx_dev_aggregate_wta_pair)."""
-        L, P, st = self.lib, C.byref(self.params), _stream()
-        _lib.check(L.smx_dev_aggregate_wta_pair(
-            P, _dp(gray_l), _dp(gray_r), self.w, self.h, self.dminl, self.dminr, self.s_begin,
-            self.s_end, _dp(self.keys), _dp(self.mean), _dp(self.agg), _dp(self.ws), self.ws_bytes, st))
+        with self._on_device():
+            L, P, st = self.lib, C.byref(self.params), self._stream()
+            _lib.check(L.smx_dev_aggregate_wta_pair(
+                P, _dp(gray_l), _dp(gray_r), self.w, self.h, self.dminl, self.dminr, self.s_begin,
+                self.s_end, _dp(self.keys), _dp(self.mean), _dp(self.agg), _dp(self.ws), self.ws_bytes, st))
 
     def init_keys(self):
-        _lib.check(self.lib.smx_dev_init_keys(_dp(self.keys), 2 * self.n, _stream()))
+        with self._on_device():
+            _lib.check(self.lib.smx_dev_init_keys(_dp(self.keys), 2 * self.n, self._stream()))
 
     def aggregate_view(self, view, guide, other, cost=None):
-        L, P, st = self.lib, C.byref(self.params), _stream()
         dmin = self.dminl if view == 0 else self.dminr
         agg = self.agg[view] if self.agg is not None else None
-        _lib.check(L.smx_dev_aggregate_wta(
-            P, _dp(guide), _dp(other), _dp(cost), self.w, self.h, dmin, self.s_begin, self.s_end,
-            _dp(self.keys[view]), _dp(self.mean[view]), _dp(agg), _dp(self.ws), self.ws_bytes, st))
+        with self._on_device():
+            L, P, st = self.lib, C.byref(self.params), self._stream()
+            _lib.check(L.smx_dev_aggregate_wta(
+                P, _dp(guide), _dp(other), _dp(cost), self.w, self.h, dmin, self.s_begin, self.s_end,
+                _dp(self.keys[view]), _dp(self.mean[view]), _dp(agg), _dp(self.ws), self.ws_bytes, st))
 
     def finish(self):
         """Keys -> best/dmap (reference presets, dispSelect rule), LR check, filling."""
-        L, P, st = self.lib, C.byref(self.params), _stream()
-        _lib.check(L.smx_dev_init_wta(_dp(self.best), _dp(self.dmap), 2 * self.n, st))
-        _lib.check(L.smx_dev_apply_keys(_dp(self.keys[0]), self.n, self.dminl, _dp(self.best[0]),
-                                        _dp(self.dmap[0]), st))
-        _lib.check(L.smx_dev_apply_keys(_dp(self.keys[1]), self.n, self.dminr, _dp(self.best[1]),
-                                        _dp(self.dmap[1]), st))
-        self.occlusion.copy_(self.dmap[0])                                   # main.cu:141
-        _lib.check(L.smx_dev_detect_occlusion(P, _dp(self.occlusion), _dp(self.dmap[1]),
-                                              self.dminl - 100, self.w, self.h, st))  # main.cu:149
-        self.filled.copy_(self.occlusion)                                    # main.cu:153
-        _lib.check(L.smx_dev_fill_occlusion(_dp(self.filled), self.w, self.h, float(self.dminl), st))
+        with self._on_device():
+            L, P, st = self.lib, C.byref(self.params), self._stream()
+            _lib.check(L.smx_dev_init_wta(_dp(self.best), _dp(self.dmap), 2 * self.n, st))
+            _lib.check(L.smx_dev_apply_keys(_dp(self.keys[0]), self.n, self.dminl, _dp(self.best[0]),
+                                            _dp(self.dmap[0]), st))
+            _lib.check(L.smx_dev_apply_keys(_dp(self.keys[1]), self.n, self.dminr, _dp(self.best[1]),
+                                            _dp(self.dmap[1]), st))
+            self.occlusion.copy_(self.dmap[0])                                   # main.cu:141
+            _lib.check(L.smx_dev_detect_occlusion(P, _dp(self.occlusion), _dp(self.dmap[1]),
+                                                  self.dminl - 100, self.w, self.h, st))  # main.cu:149
+            self.filled.copy_(self.occlusion)                                    # main.cu:153
+            _lib.check(L.smx_dev_fill_occlusion(_dp(self.filled), self.w, self.h, float(self.dminl), st))
 
     def run(self, gray_l, gray_r):
         self.aggregate(gray_l, gray_r)
         self.finish()
 
-    # -- key helpers for the shard merge -------------------------------------------------------
-    def keys_signed(self):
-        """In place: u64 keys -> order-preserving i64 (flip the top bit) for a signed MIN reduce."""
-        self.keys.bitwise_xor_(_I64_MIN)
-        return self.keys
-
-    def keys_unsigned(self):
-        self.keys.bitwise_xor_(_I64_MIN)
-        return self.keys
-
     def check_status(self):
         """Raise if a workgroup of the fused aggregation gave up waiting for a neighbour."""
         torch.cuda.synchronize(self.device)
-        _lib.check(self.lib.smx_dev_agg_status(_dp(self.ws)))
+        with self._on_device():
+            _lib.check(self.lib.smx_dev_agg_status(_dp(self.ws)))
 
     def results(self):
         """Host copies (numpy) named like the oracle's dict."""

@@ -6,7 +6,17 @@
 //
 //   smx_main                         reference behaviour: ./data/tsukuba0.png, ./data/tsukuba1.png,
 //                                    D_MIN..D_MAX from the macros, outputs into ./data/
-//   smx_main L.png R.png [dmin dmax [outdir]]
+//   smx_main L.png R.png [dmin dmax [outdir]] [options]
+// options (not in the reference):
+//   --fused           one device-resident call for everything after the gray conversion
+//                     (smx_stereo_pair: cost built on the fly inside the fused aggregation) instead of
+//                     the reference's stage-by-stage host round trips
+//   --host-compare    the reference's self-check mode (main.cu:40 hard-codes it off): every stage also
+//                     runs its CPU twin (cpu_twins.cpp) and check_errors() compares exactly
+//   --pfm FILE        filled left disparity (positive pixels) as a Middlebury-style PFM
+//   --png16 FILE      filled left disparity as a KITTI-style 16-bit PNG (disparity * 256)
+//   --ngpu N          disparity-shard the aggregation over N GPUs of this node (needs libsmx_rccl.so;
+//                     see INTEGRATION.md); N = 1 is the default single-GPU path
 #include <vector>
 
 #include "costVolume.cuh"
@@ -53,10 +63,39 @@ bool load_pair(const std::string& left, const std::string& right, Pair& p) {
     return p.rgb[0] && p.rgb[1] && p.channels[0] >= 3 && p.channels[1] >= 3 && p.w == w2 && p.h == h2;
 }
 
+struct Options {
+    std::vector<std::string> positional;
+    bool fused = false, host_compare = false;
+    std::string pfm, png16;
+    int ngpu = 1;
+    bool ok = true;
+};
+
+Options parse(int argc, char** argv) {
+    Options o;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto value = [&](std::string& dst) {
+            if (i + 1 < argc) dst = argv[++i];
+            else { std::fprintf(stderr, "%s needs a value\n", a.c_str()); o.ok = false; }
+        };
+        if (a == "--fused") o.fused = true;
+        else if (a == "--host-compare") o.host_compare = true;
+        else if (a == "--pfm") value(o.pfm);
+        else if (a == "--png16") value(o.png16);
+        else if (a == "--ngpu") { std::string v; value(v); o.ngpu = std::atoi(v.c_str()); }
+        else if (a.rfind("--", 0) == 0) { std::fprintf(stderr, "unknown option %s\n", a.c_str()); o.ok = false; }
+        else o.positional.push_back(a);
+    }
+    return o;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
-    const bool host_compare = false;          // main.cu:40 (the reference hard-codes false too)
+    const Options opt = parse(argc, argv);
+    if (!opt.ok) return 2;
+    const bool host_compare = opt.host_compare;   // main.cu:40 (the reference hard-codes false)
     std::printf("Starting...\n");
     if (smx_device_count() < 1) {
         std::fprintf(stderr, "no HIP device available\n");
@@ -65,10 +104,24 @@ int main(int argc, char** argv) {
     std::printf("Using Device %d: %s\n", 0, smx_version());
 
     std::string left = "./data/tsukuba0.png", right = "./data/tsukuba1.png", outdir = "./data";
-    if (argc >= 3) { left = argv[1]; right = argv[2]; }
-    if (argc >= 5) { smx_config().d_min = std::atoi(argv[3]); smx_config().d_max = std::atoi(argv[4]); }
-    if (argc >= 6) outdir = argv[5];
+    const std::vector<std::string>& pos = opt.positional;
+    if (pos.size() >= 2) { left = pos[0]; right = pos[1]; }
+    if (pos.size() >= 4) { smx_config().d_min = std::atoi(pos[2].c_str()); smx_config().d_max = std::atoi(pos[3].c_str()); }
+    if (pos.size() >= 5) outdir = pos[4];
     const int d_lo = smx_config().d_min, d_hi = smx_config().d_max;
+    if (d_hi < d_lo || (long long)d_hi - d_lo + 1 > 4096) {
+        std::fprintf(stderr, "bad disparity range [%d, %d]: need dmin <= dmax and at most 4096 labels\n", d_lo, d_hi);
+        return 2;
+    }
+    if (opt.ngpu < 1 || opt.ngpu > smx_device_count()) {
+        std::fprintf(stderr, "--ngpu %d: this node shows %d HIP device(s)\n", opt.ngpu, smx_device_count());
+        return 2;
+    }
+    if (opt.ngpu > 1) {
+        std::fprintf(stderr, "--ngpu %d: the multi-GPU driver lives in libsmx_rccl.so (smx_stereo_pair_sharded, "
+                             "include/smx_rccl.h); this binary was linked without it\n", opt.ngpu);
+        return 2;
+    }
 
     const std::clock_t t_begin = std::clock();
     Pair in;
@@ -87,13 +140,8 @@ int main(int argc, char** argv) {
     // left volume: labels d_lo .. d_hi; right volume: labels -d_hi .. -d_lo   (main.cu:79-82)
     const int size_d = d_hi - d_lo + 1;
     const int dmin[2] = {d_lo, -d_hi};
-    std::vector<float> cost[2] = {std::vector<float>((size_t)n * size_d), std::vector<float>((size_t)n * size_d)};
-    std::cout << "Cost Volume ..." << std::endl;
-    compute_cost(gray[0], gray[1], cost[0].data(), w, w, h, h, dmin[0], host_compare);
-    compute_cost(gray[1], gray[0], cost[1].data(), w, w, h, h, dmin[1], host_compare);
-
     // WTA presets of main.cu:112-118: memset(best, 9999999.0f) stores byte 0x7F everywhere
-    std::vector<float> best[2], dmap[2];
+    std::vector<float> best[2], dmap[2], cost[2];
     std::vector<unsigned char> mean[2], unused_u8[2];
     for (int v = 0; v < 2; ++v) {
         best[v].resize(n);
@@ -102,18 +150,51 @@ int main(int argc, char** argv) {
         mean[v].assign(n, 0);
         unused_u8[v].assign(n, 0);
     }
-    std::cout << "guided filter ..." << std::endl;
-    for (int v = 0; v < 2; ++v)
-        compute_guided_filter(gray[v], cost[v].data(), best[v].data(), dmap[v].data(), mean[v].data(), w, h,
-                              size_d, dmin[v], host_compare);
-    std::cout << "guided filter ok" << std::endl;
-
-    // left-right check on a copy of the left map, then scan-line filling on a copy of that
-    std::vector<float> occlusion(dmap[0]);
-    detect_occlusion(occlusion.data(), dmap[1].data(), dmin[0] - 100, unused_u8[0].data(),
-                     unused_u8[1].data(), w, h);                                   // main.cu:149-150
-    std::vector<float> filled(occlusion);
-    fill_occlusion(filled.data(), w, h, (float)d_lo);                              // main.cu:154-155
+    std::vector<float> occlusion, filled;
+    if (!opt.fused) {
+        // the reference's data flow: every stage is a host -> device -> host round trip
+        for (int v = 0; v < 2; ++v) cost[v].resize((size_t)n * size_d);
+        std::cout << "Cost Volume ..." << std::endl;
+        compute_cost(gray[0], gray[1], cost[0].data(), w, w, h, h, dmin[0], host_compare);
+        compute_cost(gray[1], gray[0], cost[1].data(), w, w, h, h, dmin[1], host_compare);
+        std::cout << "guided filter ..." << std::endl;
+        for (int v = 0; v < 2; ++v)
+            compute_guided_filter(gray[v], cost[v].data(), best[v].data(), dmap[v].data(), mean[v].data(), w, h,
+                                  size_d, dmin[v], host_compare);
+        std::cout << "guided filter ok" << std::endl;
+        // left-right check on a copy of the left map, then scan-line filling on a copy of that
+        occlusion = dmap[0];
+        detect_occlusion(occlusion.data(), dmap[1].data(), dmin[0] - 100, unused_u8[0].data(),
+                         unused_u8[1].data(), w, h);                                   // main.cu:149-150
+        filled = occlusion;
+        fill_occlusion(filled.data(), w, h, (float)d_lo);                              // main.cu:154-155
+    } else {
+        // device-resident: one call, the cost slices never leave the CU (only slice 0 of each volume
+        // is materialised, for the two cost images the reference writes)
+        std::cout << "Cost Volume ..." << std::endl;
+        for (int v = 0; v < 2; ++v) cost[v].resize((size_t)n);
+        CHECK(smx_compute_cost(&smx_config().params, gray[0], gray[1], cost[0].data(), w, w, h, h, 1, dmin[0]));
+        CHECK(smx_compute_cost(&smx_config().params, gray[1], gray[0], cost[1].data(), w, w, h, h, 1, dmin[1]));
+        std::cout << "guided filter ..." << std::endl;
+        occlusion.resize(n);
+        filled.resize(n);
+        smx_pair_out out;
+        std::memset(&out, 0, sizeof(out));
+        out.best_l = best[0].data(); out.best_r = best[1].data();
+        out.dmap_l = dmap[0].data(); out.dmap_r = dmap[1].data();
+        out.mean_l = mean[0].data(); out.mean_r = mean[1].data();
+        out.occlusion = occlusion.data(); out.filled = filled.data();
+        CHECK(smx_stereo_pair(&smx_config().params, gray[0], gray[1], w, h, size_d, dmin[0], dmin[1], &out));
+        std::cout << "guided filter ok" << std::endl;
+        if (host_compare) {
+            std::vector<float> lr(dmap[0]);
+            detect_occlusionOnCPU(lr.data(), dmap[1].data(), dmin[0] - 100, w, h);
+            bool ok = check_errors(lr.data(), occlusion.data(), n);
+            fill_occlusionOnCPU(lr.data(), w, h, (float)d_lo);
+            ok = check_errors(lr.data(), filled.data(), n) && ok;
+            if (ok) std::cout << "Occlusion ok!" << std::endl;
+        }
+    }
     const double duration = (std::clock() - t_begin) / (double)CLOCKS_PER_SEC;
 
     std::cout << "writing images ..." << std::endl;
@@ -127,14 +208,34 @@ int main(int argc, char** argv) {
                                   {"cost_lminus15.png", cost[0].data()},    {"cost_rminus15.png", cost[1].data()},
                                   {"occlu_mapl.png", occlusion.data()},     {"disparity_mapl.png", dmap[0].data()},
                                   {"disparity_mapr.png", dmap[1].data()},   {"occlu_mapl_filled.png", filled.data()}};
-    for (const U8Out& o : u8_outputs) smx_png_write((outdir + "/" + o.name).c_str(), w, h, 1, o.data);
+    int write_failures = 0;
+    for (const U8Out& o : u8_outputs)
+        if (!smx_png_write((outdir + "/" + o.name).c_str(), w, h, 1, o.data)) ++write_failures;
     for (const F32Out& o : f32_outputs) {
         const std::vector<unsigned char> img = normalise_like_reference(o.data, (size_t)n);
-        smx_png_write((outdir + "/" + o.name).c_str(), w, h, 1, img.data());
+        if (!smx_png_write((outdir + "/" + o.name).c_str(), w, h, 1, img.data())) ++write_failures;
+    }
+    // disparity outputs in dataset conventions: positive pixel offsets of the filled left map
+    if (!opt.pfm.empty()) {
+        std::vector<float> d(n);
+        for (int i = 0; i < n; ++i) d[i] = -filled[i];
+        if (!smx_pfm_write(opt.pfm.c_str(), w, h, d.data())) ++write_failures;
+    }
+    if (!opt.png16.empty()) {
+        std::vector<unsigned short> d(n);
+        for (int i = 0; i < n; ++i) {
+            const float v = -filled[i] * 256.0f;
+            d[i] = (unsigned short)(v < 0.0f ? 0.0f : (v > 65535.0f ? 65535.0f : v));
+        }
+        if (!smx_png_write_gray16(opt.png16.c_str(), w, h, d.data())) ++write_failures;
     }
 
     std::cout << "duration: " << duration << std::endl;
     std::cout << "Free the memory ..." << std::endl;
     for (int v = 0; v < 2; ++v) { std::free(gray[v]); std::free(in.rgb[v]); }
+    if (write_failures) {
+        std::fprintf(stderr, "%d output file(s) could not be written (does %s exist?)\n", write_failures, outdir.c_str());
+        return 1;
+    }
     return 0;
 }

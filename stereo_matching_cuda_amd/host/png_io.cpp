@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <vector>
 
 namespace {
@@ -39,15 +40,24 @@ unsigned char* smx_png_load(const char* path, int* w, int* h, int* channels) {
     if (buf.size() < 8 || memcmp(buf.data(), sig, 8)) return nullptr;
     size_t pos = 8;
     int W = 0, H = 0, depth = 0, ctype = 0, interlace = 0;
+    bool have_ihdr = false;
     std::vector<unsigned char> idat;
     while (pos + 12 <= buf.size()) {
-        uint32_t len = be32(&buf[pos]);
+        const uint32_t len = be32(&buf[pos]);
         const unsigned char* type = &buf[pos + 4];
         const unsigned char* data = &buf[pos + 8];
-        if (pos + 12 + len > buf.size()) return nullptr;
-        if (!memcmp(type, "IHDR", 4)) {
-            W = (int)be32(data); H = (int)be32(data + 4);
+        if ((size_t)len > buf.size() || pos + 12 + (size_t)len > buf.size()) return nullptr;
+        if (!have_ihdr) {
+            // the first chunk must be a 13-byte IHDR; dimensions are bounded so that the sizes
+            // below cannot overflow or exhaust memory on a hostile file
+            if (memcmp(type, "IHDR", 4) || len != 13) return nullptr;
+            const uint32_t uw = be32(data), uh = be32(data + 4);
+            if (uw == 0 || uh == 0 || uw > SMX_PNG_MAX_DIM || uh > SMX_PNG_MAX_DIM) return nullptr;
+            W = (int)uw; H = (int)uh;
             depth = data[8]; ctype = data[9]; interlace = data[12];
+            have_ihdr = true;
+        } else if (!memcmp(type, "IHDR", 4)) {
+            return nullptr;
         } else if (!memcmp(type, "IDAT", 4)) {
             idat.insert(idat.end(), data, data + len);
         } else if (!memcmp(type, "IEND", 4)) {
@@ -56,14 +66,20 @@ unsigned char* smx_png_load(const char* path, int* w, int* h, int* channels) {
         pos += 12 + len;
     }
     int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!W || !H || depth != 8 || !ch || interlace) return nullptr;
-    const size_t stride = (size_t)W * ch;
-    std::vector<unsigned char> raw((stride + 1) * H);
+    if (!have_ihdr || depth != 8 || !ch || interlace || idat.empty()) return nullptr;
+    const size_t stride = (size_t)W * ch;                  // <= 4 * 65535
+    std::vector<unsigned char> raw;
+    try {
+        raw.resize((stride + 1) * (size_t)H);              // <= ~17 GB bound; bad_alloc is caught
+    } catch (const std::exception&) {
+        return nullptr;
+    }
     uLongf rawlen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK ||
         rawlen != raw.size())
         return nullptr;
-    unsigned char* out = (unsigned char*)malloc(stride * H);
+    unsigned char* out = (unsigned char*)malloc(stride * (size_t)H);
+    if (!out) return nullptr;
     for (int y = 0; y < H; ++y) {
         const unsigned char* in = &raw[(stride + 1) * y];
         unsigned char* cur = out + stride * y;
@@ -89,10 +105,12 @@ unsigned char* smx_png_load(const char* path, int* w, int* h, int* channels) {
     return out;
 }
 
-int smx_png_write(const char* path, int w, int h, int channels, const unsigned char* data) {
+// 8-bit (bytes_per_sample = 1) or 16-bit big-endian samples (bytes_per_sample = 2, already in file order)
+static int png_write_impl(const char* path, int w, int h, int channels, int bytes_per_sample,
+                          const unsigned char* data) {
     const int ctype = channels == 1 ? 0 : channels == 3 ? 2 : channels == 2 ? 4 : channels == 4 ? 6 : -1;
-    if (ctype < 0 || w <= 0 || h <= 0) return 0;
-    const size_t stride = (size_t)w * channels;
+    if (ctype < 0 || w <= 0 || h <= 0 || w > SMX_PNG_MAX_DIM || h > SMX_PNG_MAX_DIM || !data) return 0;
+    const size_t stride = (size_t)w * channels * bytes_per_sample;
     std::vector<unsigned char> raw((stride + 1) * h);
     for (int y = 0; y < h; ++y) {
         raw[(stride + 1) * y] = 0;  // filter type None
@@ -105,13 +123,38 @@ int smx_png_write(const char* path, int w, int h, int channels, const unsigned c
     unsigned char ihdr[13];
     ihdr[0] = w >> 24; ihdr[1] = w >> 16; ihdr[2] = w >> 8; ihdr[3] = w;
     ihdr[4] = h >> 24; ihdr[5] = h >> 16; ihdr[6] = h >> 8; ihdr[7] = h;
-    ihdr[8] = 8; ihdr[9] = (unsigned char)ctype; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+    ihdr[8] = (unsigned char)(8 * bytes_per_sample); ihdr[9] = (unsigned char)ctype; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
     chunk(out, "IHDR", ihdr, 13);
     chunk(out, "IDAT", comp.data(), clen);
     chunk(out, "IEND", nullptr, 0);
     FILE* f = fopen(path, "wb");
     if (!f) return 0;
     size_t wr = fwrite(out.data(), 1, out.size(), f);
-    fclose(f);
-    return wr == out.size();
+    const int closed = fclose(f);
+    return wr == out.size() && closed == 0;
+}
+
+int smx_png_write(const char* path, int w, int h, int channels, const unsigned char* data) {
+    return png_write_impl(path, w, h, channels, 1, data);
+}
+
+// 16-bit gray PNG (KITTI disparity convention: value = disparity * 256, 0 = invalid)
+int smx_png_write_gray16(const char* path, int w, int h, const unsigned short* data) {
+    if (w <= 0 || h <= 0 || !data) return 0;
+    std::vector<unsigned char> be((size_t)w * h * 2);
+    for (size_t i = 0; i < (size_t)w * h; ++i) {
+        be[2 * i] = (unsigned char)(data[i] >> 8);
+        be[2 * i + 1] = (unsigned char)(data[i] & 0xFF);
+    }
+    return png_write_impl(path, w, h, 1, 2, be.data());
+}
+
+// Portable float map (Middlebury disparity convention): "Pf", little-endian (scale -1), rows bottom-up
+int smx_pfm_write(const char* path, int w, int h, const float* data) {
+    if (w <= 0 || h <= 0 || !data) return 0;
+    FILE* f = fopen(path, "wb");
+    if (!f) return 0;
+    bool ok = fprintf(f, "Pf\n%d %d\n-1.0\n", w, h) > 0;
+    for (int y = h - 1; y >= 0 && ok; --y) ok = fwrite(data + (size_t)y * w, sizeof(float), (size_t)w, f) == (size_t)w;
+    return (fclose(f) == 0) && ok;
 }

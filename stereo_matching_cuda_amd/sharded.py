@@ -4,14 +4,12 @@ gloo on CPU).  No reference counterpart (the reference is single-GPU); SURVEY.md
 
 Rank g of G owns the contiguous slice range [g*D//G, (g+1)*D//G) of BOTH volumes; the two gray
 images are replicated and the guidance statistics recomputed per rank (deterministic, bit-equal).
-The min of the packed keys is exactly the sequential `best >= q` rule of dispSelectOnGPU
+The signed min of the packed keys is exactly the sequential `best >= q` rule of dispSelectOnGPU
 (guidedFilter.cu:403-411): smallest cost, and among equal costs the largest slice.
 """
 import numpy as np
 import torch
 import torch.distributed as dist
-
-_I64_MIN = -(1 << 63)
 
 
 def shard_range(size_d, rank, world):
@@ -19,16 +17,11 @@ def shard_range(size_d, rank, world):
     return (rank * size_d) // world, ((rank + 1) * size_d) // world
 
 
-def keys_to_signed(keys):
-    """u64 key bits held in an int64 tensor -> order-preserving signed form (flip the top bit)."""
-    return keys ^ _I64_MIN
-
-
 def allreduce_min_keys_(keys_i64, group=None):
-    """In-place MIN all-reduce of packed keys stored as int64 bit patterns (u64 order).
-    Device tensors go through RCCL (backend "nccl"); with a gloo group (CPU rehearsal of the N>1
-    path, several ranks sharing one GPU) they are staged through host memory."""
-    keys_i64.bitwise_xor_(_I64_MIN)
+    """In-place MIN all-reduce of packed int64 keys (the kernels emit them in signed order, so this
+    is the collective and nothing else).  Device tensors go through RCCL (backend "nccl"); with a
+    gloo group (CPU rehearsal of the N>1 path, several ranks sharing one GPU) they are staged
+    through host memory."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if keys_i64.is_cuda and dist.get_backend(group) == "gloo":
             host = keys_i64.cpu()
@@ -36,15 +29,14 @@ def allreduce_min_keys_(keys_i64, group=None):
             keys_i64.copy_(host)
         else:
             dist.all_reduce(keys_i64, op=dist.ReduceOp.MIN, group=group)
-    keys_i64.bitwise_xor_(_I64_MIN)
     return keys_i64
 
 
 def merge_keys_host(key_arrays):
-    """Reference merge for tests: elementwise u64 min over a list of numpy uint64 arrays."""
-    out = np.asarray(key_arrays[0], dtype=np.uint64).copy()
+    """Reference merge for tests: elementwise signed min over a list of numpy int64 arrays."""
+    out = np.asarray(key_arrays[0], dtype=np.int64).copy()
     for k in key_arrays[1:]:
-        np.minimum(out, np.asarray(k, dtype=np.uint64), out=out)
+        np.minimum(out, np.asarray(k, dtype=np.int64), out=out)
     return out
 
 

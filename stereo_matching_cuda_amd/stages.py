@@ -69,6 +69,19 @@ def integral(image):
     return out
 
 
+def filter(image, params=None):
+    """The reference's dead `filter()` (filter.cu:117-207): direct zero-padded box filter.
+    Returns (mean u8, var f32) like its two output arguments."""
+    image = _c(image, np.uint8)
+    if image.ndim != 2:
+        raise ValueError("filter expects an (h, w) uint8 image")
+    h, w = image.shape
+    mean = np.empty((h, w), np.uint8)
+    var = np.empty((h, w), np.float32)
+    _lib.check(_lib.lib().smx_filter(C.byref(_params(params)), _ptr(image), w, h, _ptr(mean), _ptr(var)))
+    return mean, var
+
+
 def init_wta(h, w):
     """best/dmap presets of main.cu:112-118."""
     best = np.full((h, w), WTA_INIT_BITS, np.uint32).view(np.float32)

@@ -61,9 +61,9 @@ def test_nan_cost_never_wins(lib, orc):
     nan_pos = np.float32(np.nan)
     nan_neg = np.array([0xFFC00000], np.uint32).view(np.float32)[0]
     for v in (nan_pos, nan_neg):
-        assert lib.smx_pack_key(float(v), 3) == 0xFFFFFFFFFFFFFFFF
-        assert int(orc.lib().orc_pack_key(float(v), 3)) == 0xFFFFFFFFFFFFFFFF
-    assert int(orc.pack_keys(np.array([nan_neg, 1.0], np.float32), [3, 4])[0]) == 0xFFFFFFFFFFFFFFFF
+        assert lib.smx_pack_key(float(v), 3) == orc.KEY_IDENTITY
+        assert int(orc.lib().orc_pack_key(float(v), 3)) == orc.KEY_IDENTITY
+    assert int(orc.pack_keys(np.array([nan_neg, 1.0], np.float32), [3, 4])[0]) == orc.KEY_IDENTITY
 
 
 def test_argument_errors_do_not_need_a_gpu(lib):

@@ -183,6 +183,22 @@ def test_detect_occlusion_random(orc):
 
 # ---------------------------------------------------------------------------------------------
 # whole pair (main.cu:65-155), host-pointer entry and device-resident pipeline
+@pytest.mark.parametrize("w,h,radius", [(384, 288, 9), (1, 1, 9), (40, 7, 9), (63, 65, 4), (20, 20, 0)])
+def test_filter_dead_code_of_the_reference(tsukuba_gray, orc, w, h, radius):
+    """filter() (filter.cu:117-207) is never called by main.cu; kept as a standalone op."""
+    if (w, h) == (384, 288):
+        I = tsukuba_gray[0]
+    else:
+        I = np.random.default_rng(w + h).integers(0, 256, size=(h, w), dtype=np.uint8)
+    p = smx.default_params()
+    p.radius = radius
+    po = orc.Params.from_buffer_copy(bytes(p))
+    mean, var = smx.filter(I, params=p)
+    wm, wv = orc.filter(I, params=po)
+    _eq(mean, wm, "filter mean")
+    _eq(var, wv, "filter var")
+
+
 # ---------------------------------------------------------------------------------------------
 KEYS = ("meanl", "meanr", "bestl", "bestr", "dmapl", "dmapr", "occlusion", "filled")
 
@@ -442,10 +458,9 @@ def test_virtual_shards_merge_to_the_unsharded_result(tsukuba_gray, tsukuba_orac
             s0, s1 = shard_range(16, g, G)
             pipe = PairPipeline(384, 288, 16, dminl=-15, dminr=0, s_begin=s0, s_end=s1)
             pipe.aggregate(dl, dr)
-            k = pipe.keys_signed().clone()
+            k = pipe.keys.clone()
             merged = k if merged is None else torch.minimum(merged, k)
         pipe.keys.copy_(merged)
-        pipe.keys_unsigned()
         pipe.finish()
         r = pipe.results()
         for k in ("bestl", "bestr", "dmapl", "dmapr", "occlusion", "filled"):
@@ -487,10 +502,9 @@ def test_pair_motorcycle_shape_properties():
         s0, s1 = shard_range(D, g, 2)
         pipe = PairPipeline(w, h, D, s_begin=s0, s_end=s1, slices_in_flight=35)
         pipe.aggregate(dl, dr)
-        k = pipe.keys_signed().clone()
+        k = pipe.keys.clone()
         merged = k if merged is None else torch.minimum(merged, k)
     pipe.keys.copy_(merged)
-    pipe.keys_unsigned()
     assert torch.equal(pipe.keys, keys_full)
     pipe.finish()
     r = pipe.results()
@@ -514,10 +528,9 @@ def test_kitti_shape_virtual_shards_equal_the_oracle(orc):
             s0, s1 = shard_range(D, g, G)
             pipe = PairPipeline(w, h, D, s_begin=s0, s_end=s1)
             pipe.aggregate(dl, dr)
-            k = pipe.keys_signed().clone()
+            k = pipe.keys.clone()
             merged = k if merged is None else torch.minimum(merged, k)
         pipe.keys.copy_(merged)
-        pipe.keys_unsigned()
         pipe.finish()
         r = pipe.results()
         for k in KEYS:
@@ -550,13 +563,12 @@ def test_pair_4k_shape_properties():
         pipe = PairPipeline(w, h, D, s_begin=s0, s_end=s1, slices_in_flight=24)   # 64 slices, 3 chunks
         pipe.aggregate(dl, dr)
         pipe.check_status()
-        k = pipe.keys_signed().clone()
+        k = pipe.keys.clone()
         merged = k if merged is None else torch.minimum(merged, k)
         if g < 7:
             del pipe
             torch.cuda.empty_cache()
     pipe.keys.copy_(merged)
-    pipe.keys_unsigned()
     assert torch.equal(pipe.keys, keys_full)
     pipe.finish()
     r = pipe.results()

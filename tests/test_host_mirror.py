@@ -13,12 +13,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HOST = os.path.join(ROOT, "stereo_matching_cuda_amd", "host")
 BIN = os.path.join(ROOT, "stereo_matching_cuda_amd", "_build", "smx_main")
 
-REFERENCE_SIGNATURES = {   # reference header -> function names it must still declare
-    "rgb_to_grayscale.cuh": ["rgb_to_grayscale"],
-    "costVolume.cuh": ["compute_cost"],
-    "guidedFilter.cuh": ["compute_guided_filter"],
-    "integral.cuh": ["integral"],
-    "occlusion.cuh": ["detect_occlusion", "fill_occlusion"],
+REFERENCE_SIGNATURES = {   # reference header -> host function names it must still declare
+    "rgb_to_grayscale.cuh": ["rgb_to_grayscale", "sumArraysOnHost", "check_errors_grayscale"],
+    "costVolume.cuh": ["compute_cost", "costVolumeOnCPU", "x_derivativeCPU", "iDivUp",
+                       "compute_costVolumeOnCpu", "x_derivativeOnCpu"],
+    "guidedFilter.cuh": ["compute_guided_filter", "dispSelectOnCPU", "computeBoxFilterOnCPU",
+                         "computeMeanOnCPU", "chToFlOnCPU", "flToChOnCPU", "pixelMultOnCPU",
+                         "pixelSousOnCPU", "pixelAddOnCPU", "pixelDivOnCPU", "guided_filter_onCpu"],
+    "integral.cuh": ["integral", "integralOnCPU"],
+    "occlusion.cuh": ["detect_occlusion", "fill_occlusion", "detect_occlusionOnCPU", "fill_occlusionOnCPU"],
     "filter.cuh": ["filter"],
     "helpers.cuh": ["check_errors"],
     "winner_take_all.cuh": ["wta_pack"],
@@ -56,14 +59,162 @@ def test_main_fails_loudly_without_gpu(binary, tmp_path):
     assert r.returncode != 0 and "no HIP device" in r.stderr
 
 
+def _build(out, sources, shared=False):
+    inc = ["-I" + os.path.join(ROOT, "include"), "-I" + HOST]
+    lib = os.path.join(ROOT, "stereo_matching_cuda_amd", "_build")
+    cmd = (["g++", "-O2", "-std=c++17", "-ffp-contract=off"] + (["-shared", "-fPIC"] if shared else []) + inc +
+           sources + ["-o", out, "-L" + lib, "-lsmx_hip", "-lz", "-Wl,-rpath," + lib])
+    subprocess.check_call(cmd)
+    return out
+
+
+def test_cpu_twins_of_the_host_compare_mode_equal_the_oracle(binary, golden, orc, tmp_path):
+    """The CPU twins behind host_gpu_compare (host/cpu_twins.cpp; reference declarations
+    costVolume.cuh:8-14, guidedFilter.cuh:9-39, integral.cuh:7, occlusion.cuh:12,19) are product code:
+    hold them against the oracle on a Tsukuba crop, no GPU needed."""
+    import ctypes as C
+    so = _build(str(tmp_path / "libtwins.so"),
+                [os.path.join(ROOT, "tests", "host_twins_capi.cpp"), os.path.join(HOST, "cpu_twins.cpp"),
+                 os.path.join(HOST, "stages.cpp")], shared=True)
+    T = C.CDLL(so)
+    vp = C.c_void_p
+    def ptr(a):
+        return a.ctypes.data_as(vp)
+    rgb = np.ascontiguousarray(golden["tsukuba0"][60:130, 100:200])
+    rgb2 = np.ascontiguousarray(golden["tsukuba1"][60:130, 100:200])
+    h, w = rgb.shape[:2]
+    g1 = np.empty((h, w), np.uint8); g2 = np.empty((h, w), np.uint8)
+    T.twin_gray(ptr(rgb), ptr(g1), h * w, rgb.shape[2])
+    T.twin_gray(ptr(rgb2), ptr(g2), h * w, rgb2.shape[2])
+    assert np.array_equal(g1, orc.gray(rgb)) and np.array_equal(g2, orc.gray(rgb2))
+    D, dmin = 6, -5
+    cost = np.empty((D, h, w), np.float32)
+    T.twin_cost(ptr(g1), ptr(g2), ptr(cost), w, h, D, dmin)
+    want_cost = orc.cost_volume(g1, g2, D, dmin)
+    assert np.array_equal(cost.view(np.uint32), want_cost.view(np.uint32))
+    S = np.empty((h, w), np.float32)
+    T.twin_integral(ptr(cost[2]), ptr(S), w, h)
+    assert np.array_equal(S.view(np.uint32), orc.integral(cost[2]).view(np.uint32))
+    best, dmap = orc.init_wta(h, w)
+    mean = np.empty((h, w), np.uint8)
+    T.twin_guided(ptr(g1), ptr(cost), ptr(best), ptr(dmap), ptr(mean), w, h, D, dmin)
+    wb, wd, wm, _ = orc.guided_filter(g1, want_cost, dmin)
+    assert np.array_equal(best.view(np.uint32), wb.view(np.uint32))
+    assert np.array_equal(dmap, wd) and np.array_equal(mean, wm)
+    dr = np.abs(dmap[:, ::-1]).copy()
+    occ = dmap.copy()
+    T.twin_detect(ptr(occ), ptr(dr), dmin - 100, w, h)
+    want_occ = orc.detect_occlusion(dmap, dr, dmin - 100)
+    assert np.array_equal(occ, want_occ)
+    T.twin_fill(ptr(occ), w, h, C.c_float(float(dmin)))
+    assert np.array_equal(occ, orc.fill_occlusion(want_occ, float(dmin)))
+
+
 @pytest.mark.gpu
-def test_drop_in_main_reproduces_the_committed_images(binary, golden, tmp_path):
-    PIL = pytest.importorskip("PIL.Image")
+def test_reference_signature_wrappers_on_the_gpu(binary, tmp_path):
+    """integral(), filter(), check_errors(), detect/fill_occlusion of host/*.cuh called from C++."""
+    exe = _build(str(tmp_path / "wrappers_check"),
+                 [os.path.join(ROOT, "tests", "host_wrappers_check.cpp"), os.path.join(HOST, "cpu_twins.cpp"),
+                  os.path.join(HOST, "stages.cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for name in ("check_errors", "integral", "filter", "occlusion"):
+        assert "ok " + name in r.stdout, r.stdout
+
+
+def _stage_tsukuba(tmp_path):
     data = tmp_path / "data"
     data.mkdir()
     for n in ("tsukuba0", "tsukuba1"):
         src = os.path.join(ROOT, "tests", "golden", "tsukuba", n + ".png")
         (data / (n + ".png")).write_bytes(open(src, "rb").read())
+    return data
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [["--fused"], ["--host-compare"], ["--fused", "--host-compare"]])
+def test_drop_in_main_modes(binary, golden, tmp_path, flags):
+    """--fused: one device-resident call after the gray conversion; --host-compare: the reference's
+    self-check mode (main.cu:40) with correct CPU twins.  Same 12 images either way."""
+    PIL = pytest.importorskip("PIL.Image")
+    data = _stage_tsukuba(tmp_path)
+    pfm = tmp_path / "d.pfm"
+    p16 = tmp_path / "d.png"
+    r = subprocess.run([binary] + flags + ["--pfm", str(pfm), "--png16", str(p16)], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "error at element" not in r.stdout
+    if "--host-compare" in flags:
+        assert "Grayscale ok!" in r.stdout
+        assert ("Occlusion ok!" if "--fused" in flags else "Guided filter ok!") in r.stdout
+    for name in OUTPUTS:
+        got = np.asarray(PIL.open(data / (name + ".png")))
+        assert np.array_equal(got, golden[name]), name
+    # dataset-style outputs: positive disparities of the filled left map
+    raw = pfm.read_bytes()
+    head, rest = raw.split(b"\n", 3)[:3], raw.split(b"\n", 3)[3]
+    assert head[0] == b"Pf" and head[1] == b"384 288" and float(head[2]) < 0
+    d = np.frombuffer(rest, "<f4").reshape(288, 384)[::-1]
+    assert d.min() >= 0 and d.max() <= 15
+    d16 = np.asarray(PIL.open(p16))
+    assert d16.dtype in (np.uint16, np.int32) and np.array_equal(d16.astype(np.float32), d * 256.0)
+
+
+def test_main_rejects_bad_arguments(binary, tmp_path):
+    import stereo_matching_cuda_amd as smx
+    r = subprocess.run([binary, "--nonsense"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode == 2 and "unknown option" in r.stderr
+    if smx.lib().smx_device_count() > 0:
+        r = subprocess.run([binary, "a.png", "b.png", "5", "-5"], cwd=tmp_path, capture_output=True, text=True)
+        assert r.returncode == 2 and "bad disparity range" in r.stderr
+
+
+@pytest.mark.gpu
+def test_main_reports_unwritable_output_directory(binary, tmp_path):
+    data = _stage_tsukuba(tmp_path)
+    r = subprocess.run([binary, str(data / "tsukuba0.png"), str(data / "tsukuba1.png"), "-3", "0",
+                        str(tmp_path / "missing_dir")], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "could not be written" in r.stderr
+
+
+def test_png_reader_rejects_malformed_files(tmp_path):
+    """host/png_io.cpp trusts nothing: truncated IHDR, absurd dimensions, missing IDAT."""
+    import struct
+    import zlib
+    exe = str(tmp_path / "pngcheck")
+    src = tmp_path / "pngcheck.cpp"
+    src.write_text('#include "png_io.h"\n#include <cstdio>\n#include <cstdlib>\n'
+                   'int main(int c, char** v) { int w, h, ch; unsigned char* p = smx_png_load(v[1], &w, &h, &ch);'
+                   ' std::printf("%s\\n", p ? "loaded" : "rejected"); std::free(p); return 0; }\n')
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I" + HOST, str(src), os.path.join(HOST, "png_io.cpp"),
+                           "-o", exe, "-lz"])
+    sig = b"\x89PNG\r\n\x1a\n"
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    good_ihdr = struct.pack(">IIBBBBB", 2, 2, 8, 0, 0, 0, 0)
+    idat = zlib.compress(b"\x00\x01\x02\x00\x03\x04")
+    cases = {
+        "ok.png": (sig + chunk(b"IHDR", good_ihdr) + chunk(b"IDAT", idat) + chunk(b"IEND", b""), "loaded"),
+        "short_ihdr.png": (sig + chunk(b"IHDR", good_ihdr[:5]) + chunk(b"IEND", b""), "rejected"),
+        "huge.png": (sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 0x7FFFFFFF, 0x7FFFFFFF, 8, 0, 0, 0, 0)) +
+                     chunk(b"IDAT", idat) + chunk(b"IEND", b""), "rejected"),
+        "negative.png": (sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 0xFFFFFFF0, 2, 8, 0, 0, 0, 0)) +
+                         chunk(b"IDAT", idat) + chunk(b"IEND", b""), "rejected"),
+        "no_idat.png": (sig + chunk(b"IHDR", good_ihdr) + chunk(b"IEND", b""), "rejected"),
+        "idat_first.png": (sig + chunk(b"IDAT", idat) + chunk(b"IHDR", good_ihdr) + chunk(b"IEND", b""), "rejected"),
+        "truncated.png": (sig + chunk(b"IHDR", good_ihdr)[:-3], "rejected"),
+    }
+    for name, (blob, want) in cases.items():
+        f = tmp_path / name
+        f.write_bytes(blob)
+        out = subprocess.run([exe, str(f)], capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.strip() == want, (name, out.stdout, out.stderr)
+
+
+@pytest.mark.gpu
+def test_drop_in_main_reproduces_the_committed_images(binary, golden, tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    data = _stage_tsukuba(tmp_path)
     r = subprocess.run([binary], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     for line in ("Starting...", "Resolution : 384x288", "RGB to grayscale ...", "Cost Volume ...",

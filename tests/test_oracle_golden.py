@@ -126,6 +126,6 @@ def test_pack_keys_match_c(orc):
     b, s2 = orc.unpack_keys(keys)
     assert np.array_equal(s2, sl)
     assert np.array_equal(b, np.where(vals == 0, np.float32(0), vals))
-    # order: smaller cost first; equal cost -> larger slice first
+    # signed order: smaller cost first; equal cost -> larger slice first
     o = np.lexsort((-sl, vals))
-    assert np.all(np.diff(keys[o].astype(np.float64)) <= 0) or np.all(keys[o][:-1] <= keys[o][1:])
+    assert keys.dtype == np.int64 and np.all(keys[o][:-1] <= keys[o][1:])

@@ -12,8 +12,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from stereo_matching_cuda_amd.sharded import (allreduce_min_keys_, keys_to_signed, merge_keys_host,
-                                              shard_range)
+from stereo_matching_cuda_amd.sharded import allreduce_min_keys_, merge_keys_host, shard_range
 
 
 def _free_port():
@@ -30,15 +29,15 @@ def _worker(rank, world, port, Il, Ir, D, dmin, out_dir):
     try:
         h, w = Il.shape
         s0, s1 = shard_range(D, rank, world)
-        keys = np.full((2, h, w), np.uint64(0xFFFFFFFFFFFFFFFF))
+        keys = np.full((2, h, w), np.int64(orc.KEY_IDENTITY))
         for view, (I, J, dm) in enumerate(((Il, Ir, dmin), (Ir, Il, 0))):
             if s1 > s0:
                 cost = orc.cost_volume(I, J, D, dm)
                 best, dmap, _, _ = orc.guided_filter(I, cost, dm, s_begin=s0, s_end=s1)
                 keys[view] = orc.pack_keys(best, (dmap - dm).astype(np.int64))
-        t = torch.from_numpy(keys.view(np.int64).copy())
+        t = torch.from_numpy(keys.copy())
         allreduce_min_keys_(t)
-        np.save(os.path.join(out_dir, f"keys{rank}.npy"), t.numpy().view(np.uint64))
+        np.save(os.path.join(out_dir, f"keys{rank}.npy"), t.numpy())
     finally:
         dist.destroy_process_group()
 
@@ -75,10 +74,10 @@ def test_signed_key_order_and_tie_break(orc):
     cost = np.concatenate([rng.normal(size=64), [0.0, -0.0, 1.5, 1.5, 1.5, -2.0, 3.3961514e38]]).astype(np.float32)
     sl = rng.integers(0, 512, size=cost.size)
     k = orc.pack_keys(cost, sl)
-    ks = keys_to_signed(torch.from_numpy(k.view(np.int64).copy())).numpy()
-    order_u = np.argsort(k, kind="stable")
-    order_s = np.argsort(ks, kind="stable")
-    assert np.array_equal(order_u, order_s)
+    assert k.dtype == np.int64
+    # the signed order of the keys is (cost ascending, slice descending)
+    assert np.array_equal(np.argsort(k, kind="stable"),
+                          np.lexsort((-sl, np.where(cost == 0, np.float32(0), cost))))
     # equal cost: the larger slice has the smaller key (dispSelect `>=`: later slice wins)
     a = orc.pack_keys(np.float32([1.5, 1.5]), [3, 9])
     assert a[1] < a[0]
@@ -86,7 +85,7 @@ def test_signed_key_order_and_tie_break(orc):
     b = orc.pack_keys(np.float32([1.25, 1.5]), [0, 511])
     assert b[0] < b[1]
     # identity element
-    m = merge_keys_host([k, np.full_like(k, np.uint64(0xFFFFFFFFFFFFFFFF))])
+    m = merge_keys_host([k, np.full_like(k, np.int64(orc.KEY_IDENTITY))])
     assert np.array_equal(m, k)
 
 
