@@ -4,9 +4,10 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one synthetic 1242x375 stereo pair at D=192 through the whole path: fused cost build,
-guided-filter aggregation + running WTA of both views, (N > 1: one RCCL MIN all-reduce of the packed
-keys, the disparity slices being sharded across ranks), decode, LR check, filling.  Inputs are
+A step = one synthetic 1242x375 stereo pair at D=192 through the whole path: guidance statistics, the
+fused single-kernel aggregation (cost build -> integral -> box -> a,b -> integral -> box -> q per strip,
+a and b never leave the CU), running WTA of both views, (N > 1: one RCCL MIN all-reduce of the packed
+int64 keys, the disparity slices being sharded across ranks), decode, LR check, filling.  Inputs are
 resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 roofline: the aggregation operator (smx_dev_aggregate_wta_pair: left + right volume) against HBM:
@@ -117,12 +118,16 @@ def main():
     # correction calibrated on a kernel with a known byte count).  Only valid for the profiled config.
     traffic = None
     traffic_src = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if world == 1 and args.workload == "kitti" and pipe.slices_in_flight == D and os.path.exists(tpath):
+    tname = {"kitti": "r02_traffic.json", "motorcycle": "r02_motorcycle_traffic.json",
+             "4k": "r02_4k_traffic.json"}.get(args.workload)
+    tpath = os.path.join(ROOT, "profiles", tname) if tname else None
+    if world == 1 and tpath and args.slices_in_flight is None and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             traffic = float(tj["aggregation_call_hbm_bytes"])
-            traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+            traffic_src = (f"profiles/{tname}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in "
+                           "separate passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the kernels of one call "
+                           "(tools/gpu_suite.sh, tools/traffic.py)")
         except (ValueError, KeyError):
             traffic = None
 
@@ -176,10 +181,20 @@ def main():
             reps += 1
         cdt = total_t / reps
         scale = D / sample_d
+        cpu_model, cpu_total = "unknown", os.cpu_count()
+        try:
+            for line in open("/proc/cpuinfo"):
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
         result["cpu_baseline"] = {
             "value": (w * h) / (cdt * scale) / 1e6,
             "unit": "MPix/s",
             "cores": 1,
+            "host_cpu": cpu_model,
+            "host_logical_cpus": cpu_total,
             "kind": "port",
             "sample": (f"oracle/smx_oracle.c (gcc -O2 -ffp-contract=off), 1 thread, same pair, "
                        f"{sample_d} of {D} disparities per view"

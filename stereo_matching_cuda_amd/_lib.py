@@ -8,8 +8,15 @@ import ctypes as C
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-# SMX_LIB_PATH: load another build of the same C-ABI (timing-experiment builds, tools/exp_build.sh)
-SO_PATH = os.environ.get("SMX_LIB_PATH") or os.path.join(_PKG, "_build", "libsmx_hip.so")
+# The product library.  Diagnostic builds of the same C-ABI (tools/v3_stamps.sh: in-kernel stamps) are
+# loaded only when BOTH SMX_LIB_PATH and SMX_ALLOW_LIB_OVERRIDE=1 are set, so that one stray variable
+# cannot make the tests run against a different binary.
+SO_PATH = os.path.join(_PKG, "_build", "libsmx_hip.so")
+if os.environ.get("SMX_LIB_PATH"):
+    if os.environ.get("SMX_ALLOW_LIB_OVERRIDE") != "1":
+        raise ImportError("SMX_LIB_PATH is set but SMX_ALLOW_LIB_OVERRIDE=1 is not: refusing to load a "
+                          "non-product build of libsmx_hip.so")
+    SO_PATH = os.environ["SMX_LIB_PATH"]
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "smx.h")
 
 

@@ -15,8 +15,11 @@
 //                     runs its CPU twin (cpu_twins.cpp) and check_errors() compares exactly
 //   --pfm FILE        filled left disparity (positive pixels) as a Middlebury-style PFM
 //   --png16 FILE      filled left disparity as a KITTI-style 16-bit PNG (disparity * 256)
-//   --ngpu N          disparity-shard the aggregation over N GPUs of this node (needs libsmx_rccl.so;
-//                     see INTEGRATION.md); N = 1 is the default single-GPU path
+//   --ngpu N          disparity-shard the aggregation over N GPUs of this node: every GPU aggregates
+//                     its slice range, ONE RCCL MIN all-reduce of the packed keys reassembles the map
+//                     (smx_stereo_pair_sharded in libsmx_rccl.so, loaded on demand; implies --fused)
+#include <dlfcn.h>
+
 #include <vector>
 
 #include "costVolume.cuh"
@@ -67,7 +70,7 @@ struct Options {
     std::vector<std::string> positional;
     bool fused = false, host_compare = false;
     std::string pfm, png16;
-    int ngpu = 1;
+    int ngpu = 0;            // 0 = not given: the single-GPU paths
     bool ok = true;
 };
 
@@ -113,15 +116,23 @@ int main(int argc, char** argv) {
         std::fprintf(stderr, "bad disparity range [%d, %d]: need dmin <= dmax and at most 4096 labels\n", d_lo, d_hi);
         return 2;
     }
-    if (opt.ngpu < 1 || opt.ngpu > smx_device_count()) {
+    if (opt.ngpu < 0 || opt.ngpu > smx_device_count()) {
         std::fprintf(stderr, "--ngpu %d: this node shows %d HIP device(s)\n", opt.ngpu, smx_device_count());
         return 2;
     }
-    if (opt.ngpu > 1) {
-        std::fprintf(stderr, "--ngpu %d: the multi-GPU driver lives in libsmx_rccl.so (smx_stereo_pair_sharded, "
-                             "include/smx_rccl.h); this binary was linked without it\n", opt.ngpu);
-        return 2;
+    // the multi-GPU driver (RCCL) is loaded only when asked for, so the plain binary does not need librccl
+    typedef int (*sharded_fn)(const smx_params*, const uint8_t*, const uint8_t*, int, int, int, int, int, int,
+                              const smx_pair_out*);
+    sharded_fn pair_sharded = nullptr;
+    if (opt.ngpu >= 1) {
+        void* so = dlopen("libsmx_rccl.so", RTLD_NOW | RTLD_LOCAL);
+        pair_sharded = so ? (sharded_fn)dlsym(so, "smx_stereo_pair_sharded") : nullptr;
+        if (!pair_sharded) {
+            std::fprintf(stderr, "--ngpu: cannot load smx_stereo_pair_sharded from libsmx_rccl.so (%s)\n", dlerror());
+            return 1;
+        }
     }
+    const bool fused = opt.fused || pair_sharded;
 
     const std::clock_t t_begin = std::clock();
     Pair in;
@@ -151,7 +162,7 @@ int main(int argc, char** argv) {
         unused_u8[v].assign(n, 0);
     }
     std::vector<float> occlusion, filled;
-    if (!opt.fused) {
+    if (!fused) {
         // the reference's data flow: every stage is a host -> device -> host round trip
         for (int v = 0; v < 2; ++v) cost[v].resize((size_t)n * size_d);
         std::cout << "Cost Volume ..." << std::endl;
@@ -184,7 +195,10 @@ int main(int argc, char** argv) {
         out.dmap_l = dmap[0].data(); out.dmap_r = dmap[1].data();
         out.mean_l = mean[0].data(); out.mean_r = mean[1].data();
         out.occlusion = occlusion.data(); out.filled = filled.data();
-        CHECK(smx_stereo_pair(&smx_config().params, gray[0], gray[1], w, h, size_d, dmin[0], dmin[1], &out));
+        if (pair_sharded)
+            CHECK(pair_sharded(&smx_config().params, gray[0], gray[1], w, h, size_d, dmin[0], dmin[1], opt.ngpu, &out));
+        else
+            CHECK(smx_stereo_pair(&smx_config().params, gray[0], gray[1], w, h, size_d, dmin[0], dmin[1], &out));
         std::cout << "guided filter ok" << std::endl;
         if (host_compare) {
             std::vector<float> lr(dmap[0]);

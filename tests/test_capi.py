@@ -119,3 +119,16 @@ def test_header_is_plain_c_and_links(lib, tmp_path):
                            "-Wl,-rpath," + libdir])
     out = subprocess.run([str(exe)], capture_output=True, text=True)
     assert out.returncode == 0 and "9 6.5025" in out.stdout
+
+
+def test_fast_division_is_exhaustively_bit_identical_to_ieee(tmp_path):
+    """div_small_int() of the fused kernel (x*r + one fma residual step, r = RN(1/area)) against the IEEE
+    division for all 142 window areas x every f32 significand and sign at the extreme and middle
+    exponents of the admitted range (7.2e9 cases, tools/check_fastdiv.c); smaller / non-finite x take
+    the true division in the kernel (div_needs_exact)."""
+    import subprocess
+    exe = str(tmp_path / "check_fastdiv")
+    subprocess.check_call(["gcc", "-O2", "-mfma", "-ffp-contract=off", "-fopenmp",
+                           os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_fastdiv.c"), "-lm", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " bad 0" in r.stdout, r.stdout

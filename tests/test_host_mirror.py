@@ -132,10 +132,13 @@ def _stage_tsukuba(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("flags", [["--fused"], ["--host-compare"], ["--fused", "--host-compare"]])
+@pytest.mark.parametrize("flags", [["--fused"], ["--host-compare"], ["--fused", "--host-compare"],
+                                   ["--ngpu", "1"]])
 def test_drop_in_main_modes(binary, golden, tmp_path, flags):
     """--fused: one device-resident call after the gray conversion; --host-compare: the reference's
-    self-check mode (main.cu:40) with correct CPU twins.  Same 12 images either way."""
+    self-check mode (main.cu:40) with correct CPU twins; --ngpu 1: the RCCL sharded driver of
+    libsmx_rccl.so with a one-rank communicator (the N > 1 call sequence on the one GPU of this box).
+    Same 12 images every way."""
     PIL = pytest.importorskip("PIL.Image")
     data = _stage_tsukuba(tmp_path)
     pfm = tmp_path / "d.pfm"
@@ -158,6 +161,18 @@ def test_drop_in_main_modes(binary, golden, tmp_path, flags):
     assert d.min() >= 0 and d.max() <= 15
     d16 = np.asarray(PIL.open(p16))
     assert d16.dtype in (np.uint16, np.int32) and np.array_equal(d16.astype(np.float32), d * 256.0)
+
+
+def test_rccl_library_exports_the_exchange_step():
+    """include/smx_rccl.h: the C-ABI of the multi-GPU exchange (declared in host/winner_take_all.cuh)."""
+    so = os.path.join(ROOT, "stereo_matching_cuda_amd", "_build", "libsmx_rccl.so")
+    assert os.path.exists(so), "libsmx_rccl.so not built (make -C stereo_matching_cuda_amd/csrc)"
+    syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    hdr = open(os.path.join(ROOT, "include", "smx_rccl.h")).read()
+    for name in ("smx_wta_allreduce", "smx_stereo_pair_sharded"):
+        assert re.search(r"\bT %s\b" % name, syms), name
+        assert re.search(r"\b%s\s*\(" % name, hdr), name
+    assert "smx_wta_allreduce" in open(os.path.join(HOST, "winner_take_all.cuh")).read()
 
 
 def test_main_rejects_bad_arguments(binary, tmp_path):

@@ -4,6 +4,7 @@ import numpy as np
 import torch
 sys.path.insert(0, ".")
 os.environ["SMX_LIB_PATH"] = os.path.join("stereo_matching_cuda_amd", "_build_stamps", "libsmx_hip.so")
+os.environ["SMX_ALLOW_LIB_OVERRIDE"] = "1"
 import stereo_matching_cuda_amd as smx
 from stereo_matching_cuda_amd import synth
 from stereo_matching_cuda_amd.device import PairPipeline
