@@ -314,7 +314,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
 
         if (wave == W_IO) {
             // =====================================================================================
-            // I/O wave (+ column scan of the ring columns 64 .. TW-1).
+            // I/O wave.
             // Global step index t: A(i) = 2i + 4, B(i) = 2i + 5 (i >= -2).
             // Data another strip needs (row carries, halo columns) is produced into LDS at step t by
             // the row-scan / box waves, stored to global (sc1, 16 B per lane) by this wave at the start
@@ -327,8 +327,6 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             const size_t recs = (size_t)NB * REC_F2;      // float2 per (parity, slice-view)
             const rsrc_t r_in = mk_rsrc(A.hand + ((size_t)((k - 1) & 1) * nsv + sv) * recs, recs * 8);
             const rsrc_t r_out = mk_rsrc(A.hand + ((size_t)(k & 1) * nsv + sv) * recs, recs * 8);
-            const bool ccol = lane + 64 < TW;             // this lane scans ring column lane + 64
-            f2 S1 = ident, S2 = ident;
             f4 hreg[NHU];
             f4 c1reg = {0, 0, 0, 0}, c2reg = {0, 0, 0, 0};
             int hlo = 0, hhi = 0;        // a/b rows of the halo values in hreg
@@ -389,11 +387,6 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     wait_pred(2 * i + 6);
                     if (lane < BH / 2) c1reg = ld16_sc1(r_in, (unsigned)((i + 2) * REC_F2 * 8 + lane * 16));
                 }
-                if (MODE == AGG) {
-                    rows2(i - 1, lo, hi);                  // column scan, stage 2, columns 64 ..
-                    if (i - 1 == 0) S2 = ident;
-                    if (ccol) colscan(ring2, lane + 64, lo, hi, S2);
-                }
                 V3_STAMP(0);
                 wg_barrier();
                 V3_STAMP(1);
@@ -406,11 +399,17 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     if (i + 1 >= 0 && i + 1 < NB && lane < BH / 2)
                         st16_sc1(r_out, (unsigned)((i + 1) * REC_F2 * 8 + lane * 16), *(const f4*)&cout[0][2 * lane]);
                     if (MODE == AGG && i >= 0 && i < NB) {
+                        f4 hv[NHU];
+#pragma unroll
+                        for (int e = 0; e < NHU; ++e) {          // all LDS reads first, then the stores
+                            const int t = lane + 64 * e;
+                            hv[e] = *(const f4*)&hout[2 * (t < BH * HP / 2 ? t : 0)];
+                        }
 #pragma unroll
                         for (int e = 0; e < NHU; ++e) {
                             const int t = lane + 64 * e;
                             if (t < BH * HP / 2)
-                                st16_sc1(r_out, (unsigned)((i * REC_F2 + 2 * BH) * 8 + t * 16), *(const f4*)&hout[2 * t]);
+                                st16_sc1(r_out, (unsigned)((i * REC_F2 + 2 * BH) * 8 + t * 16), hv[e]);
                         }
                     }
                 }
@@ -429,9 +428,6 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                         }
                     }
                 }
-                rows1(i + 1, lo, hi);                      // column scan, stage 1, columns 64 ..
-                if (i + 1 == 0) S1 = ident;
-                if (ccol) colscan(ring1, lane + 64, lo, hi, S1);
                 V3_STAMP(2);
                 wg_barrier();
                 V3_STAMP(3);
@@ -440,22 +436,25 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             if (succ && lane == 0) flag_store(myflag, FLAG_DONE);
         } else if (wave == W_C) {
             // =====================================================================================
-            // column-scan wave: ring columns 0 .. 63 of both stages
+            // column-scan wave: ring columns 0 .. 63, then 64 .. TW-1, of both stages
             // =====================================================================================
-            f2 S1 = ident, S2 = ident;
+            const bool ccol = lane + 64 < TW;             // this lane also scans ring column lane + 64
+            f2 S1 = ident, S2 = ident, S1b = ident, S2b = ident;
             for (int i = -2; i <= NB + 1; ++i) {
                 int lo, hi;
                 if (MODE == AGG) {
                     rows2(i - 1, lo, hi);                  // A(i): stage 2, band i-1
-                    if (i - 1 == 0) S2 = ident;
+                    if (i - 1 == 0) { S2 = ident; S2b = ident; }
                     colscan(ring2, lane, lo, hi, S2);
+                    if (ccol) colscan(ring2, lane + 64, lo, hi, S2b);
                 }
                 V3_STAMP(0);
                 wg_barrier();
                 V3_STAMP(1);
                 rows1(i + 1, lo, hi);                      // B(i): stage 1, band i+1
-                if (i + 1 == 0) S1 = ident;
+                if (i + 1 == 0) { S1 = ident; S1b = ident; }
                 colscan(ring1, lane, lo, hi, S1);
+                if (ccol) colscan(ring1, lane + 64, lo, hi, S1b);
                 V3_STAMP(2);
                 wg_barrier();
                 V3_STAMP(3);
@@ -473,6 +472,38 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 f2 acc = pred ? cin[st][lane] : ident;
                 f2* row = ring + (y % RR) * PITCH;
                 int j = jlo;
+                if (jlo == 0 && jhi == TWMAX) {
+                    // the common case (a strip inside the image at radius 9): 83 columns, fully unrolled so
+                    // that every LDS wait is a counted one -- the reads of the next eight columns are in
+                    // flight while the eight dependent adds of the current batch issue
+                    constexpr int NBATCH = TWMAX / 8;                  // 10 batches of 8 + 3 columns
+                    f4 v[2][4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[0][t] = *(const f4*)(row + 2 * t);
+#pragma unroll
+                    for (int bt = 0; bt < NBATCH; ++bt) {
+                        if (bt + 1 < NBATCH) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) v[(bt + 1) & 1][t] = *(const f4*)(row + 8 * (bt + 1) + 2 * t);
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const f4 x = v[bt & 1][t];
+                            const f2 s0 = lo2(x) + acc;
+                            const f2 s1 = hi2(x) + s0;
+                            acc = s1;
+                            const f4 o = {s0.x, s0.y, s1.x, s1.y};
+                            *(f4*)(row + 8 * bt + 2 * t) = o;
+                            if (8 * bt + 2 * t + 1 == OW - 1) cout[st][lane] = s1;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 8 * NBATCH; c < TWMAX; ++c) {
+                        acc = row[c] + acc;
+                        row[c] = acc;
+                    }
+                    return;
+                }
                 if (j & 1) {
                     acc = row[j] + acc;
                     row[j] = acc;
@@ -628,9 +659,10 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 }
             }
             uint32_t ua[NE], ub[NE];
-            float ga[2], gb[2], Iv[2];
+            float ga[2], gb[2];
+            uint32_t Iraw[2];     // raw (value, gradient) halves: converted at use, a step after the load
 #pragma unroll
-            for (int t = 0; t < 2; ++t) { ga[t] = 0.0f; gb[t] = 0.0f; Iv[t] = 0.0f; }
+            for (int t = 0; t < 2; ++t) { ga[t] = 0.0f; gb[t] = 0.0f; Iraw[t] = 0; }
 #pragma unroll
             for (int e = 0; e < NE; ++e) { ua[e] = 0; ub[e] = 0; }
 
@@ -645,7 +677,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const int y = ylo + 2 * wb + t;
-                        if (y < yhi) Iv[t] = (float)FG1[(size_t)y * fgw + g2.xc + 1].x;
+                        if (y < yhi) Iraw[t] = __builtin_bit_cast(uint32_t, FG1[(unsigned)y * fgw + (unsigned)g2.xc + 1u]);
                     }
                 }
                 if (ev) {
@@ -653,10 +685,10 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     for (int e = 0; e < NE; ++e) {
                         // image row of the cell, clamped into the image (wave-uniform for e < 2)
                         const int y = e < 2 ? min(be * BH + 2 * wb + e, h - 1) : min(be * BH + 2 * wb + rsel, h - 1);
-                        const char* b1 = (const char*)(FG1 + (size_t)y * fgw);
+                        const char* b1 = (const char*)(FG1 + (unsigned)y * fgw);
                         ua[e] = *(const uint32_t*)(b1 + e_v1[e]);
                         if (MODE == AGG && SRC == SRC_IMG)
-                            ub[e] = *(const uint32_t*)((const char*)(FG2 + (size_t)y * fgw) + e_v2[e]);
+                            ub[e] = *(const uint32_t*)((const char*)(FG2 + (unsigned)y * fgw) + e_v2[e]);
                         if (MODE == AGG && SRC == SRC_COST)
                             ub[e] = *(const uint32_t*)((const char*)(V.cost + ((size_t)slice * h + y) * w) + e_v2[e]);
                     }
@@ -683,7 +715,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                             float var = m[t].y - mm;       // pixelSousOnGPU :121
                             float c = (float)(1.0f / ((double)var + A.eps));   // :350
                             if (g1.xin && ok[t]) {
-                                const size_t o = (size_t)y * w + g1.xc;
+                                const unsigned o = (unsigned)y * (unsigned)w + (unsigned)g1.xc;
                                 V.gmean[o] = m[t].x;
                                 V.gcinv[o] = c;
                                 if (V.mean_u8) {           // flToChOnGPU :451-458
@@ -715,8 +747,8 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     for (int t = 0; t < 2; ++t) {
                         const int y = ylo + 2 * wb + t;
                         if (y < yhi) {
-                            ga[t] = V.mean[(size_t)y * w + g1.xc];
-                            gb[t] = V.cinv[(size_t)y * w + g1.xc];
+                            ga[t] = V.mean[(unsigned)y * (unsigned)w + (unsigned)g1.xc];
+                            gb[t] = V.cinv[(unsigned)y * (unsigned)w + (unsigned)g1.xc];
                         }
                     }
                 }
@@ -735,8 +767,9 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                         box2(ring2, g2, xint2, yy, m);
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            float tq = m[t].x * Iv[t];     // compute_q guidedFilter.cu:363-369
-                            if (g2.xin && ok[t]) __builtin_nontemporal_store(tq + m[t].y, &qp[(size_t)yy[t] * w + g2.xc]);
+                            const float Iv = (float)__builtin_bit_cast(fg_t, Iraw[t]).x;
+                            float tq = m[t].x * Iv;        // compute_q guidedFilter.cu:363-369
+                            if (g2.xin && ok[t]) __builtin_nontemporal_store(tq + m[t].y, &qp[(unsigned)yy[t] * (unsigned)w + (unsigned)g2.xc]);
                         }
                     }
                 }

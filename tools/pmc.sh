@@ -8,9 +8,10 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" \
          "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" \
-         "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
+         "SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU SQ_INSTS_FLAT SQ_INSTS_GDS SQ_INSTS_BRANCH" \
+         "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
+  timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $OUT/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 5 "$@" > $OUT/p$i.log 2>&1 || echo "pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections
@@ -23,6 +24,7 @@ for f in glob.glob("$OUT/p*/*/*counter_collection.csv"):
         cnt[k][r["Counter_Name"]] += 1
 with open("$OUT/summary.txt", "w") as o:
     for k in sorted(agg):
+        if "v3" not in k: continue
         o.write(k + "\n")
         for c in sorted(agg[k]):
             o.write(f"   {c:28s} per-dispatch {agg[k][c]/cnt[k][c]:16.1f}  (n={cnt[k][c]})\n")
