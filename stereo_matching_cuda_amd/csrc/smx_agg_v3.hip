@@ -57,7 +57,7 @@ constexpr int BH = 2 * NWB;             // band height: every box wave owns two 
 constexpr int RR = 3 * BH;              // ring rows
 static_assert(RR >= 2 * BH + 2 * RMAX + 2, "ring too small for the two-step pipeline");
 
-enum Mode { GUID = 0, AGG = 1 };
+enum Mode { GUID = 0, AGG = 1, FUSED = 2 };   // FUSED: guidance items + aggregation items in one launch
 enum Src { SRC_IMG = 0, SRC_COST = 1 };
 
 typedef _Float16 fg_t __attribute__((ext_vector_type(2)));   // (pixel value, x-derivative), exact in fp16
@@ -79,8 +79,12 @@ struct View {
 struct Args {
     View v[2];
     int w, h, R, K, NB, nslices, nsv, nitems;
+    int nviews, nguid;    // FUSED: the first nguid = nviews * K items are the guidance items (view, strip)
     f2* hand;             // hand-off records [parity][sv][band] (see REC_F2)
+    f2* ghand;            // FUSED: hand-off records of the guidance items [parity][view][band]
     unsigned* flags;      // [sv][K]   finished-band counters (zeroed before every launch)
+    unsigned* gflags;     // FUSED: [view][K] the same for the guidance items
+    unsigned* gready;     // FUSED: [view][K] bands of mean_I / 1/(var+eps) that are complete and visible
     unsigned* ticket;     // work-item counter            (zeroed before every launch)
     unsigned* status;     // != 0: a flag wait timed out (results invalid)
     CostConst cc;
@@ -157,6 +161,7 @@ __device__ __forceinline__ void st_sc1(rsrc_t r, unsigned byteoff, f2 v) {
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2, v), r, (int)byteoff, 0, AUX_SC1);
 }
 typedef __attribute__((address_space(1))) unsigned gu32;
+typedef __attribute__((address_space(1))) float gf32;
 __device__ __forceinline__ unsigned flag_load(unsigned* p) {
     return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -243,13 +248,13 @@ static_assert(BH == 2 * NWB, "every box wave owns two rows of a band");
 template <int MODE, int SRC>
 __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
     __shared__ __attribute__((aligned(16))) f2 ring1[RR * PITCH];
-    __shared__ __attribute__((aligned(16))) f2 ring2[MODE == AGG ? RR * PITCH : 2];
+    __shared__ __attribute__((aligned(16))) f2 ring2[MODE != GUID ? RR * PITCH : 2];
     // hand-off staging (all global hand-off traffic goes through the I/O wave, one step delayed):
     __shared__ __attribute__((aligned(16))) f2 cin[2][BH];    // row carries in : stage -> rows of the band
     __shared__ __attribute__((aligned(16))) f2 cout[2][BH];   // row carries out
     __shared__ __attribute__((aligned(16))) f2 hout[BH * HP]; // last 2R+1 columns of a, b of the band (AGG)
     __shared__ float rcp_s[HWMAX * HWMAX + 1];                // RN(1/area)
-    __shared__ int s_item;
+    __shared__ int s_item, s_next;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -264,16 +269,26 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
     // issue arbitration against the box waves that share their SIMDs
     if (wave < W_B0) __builtin_amdgcn_s_setprio(3);
 
+    // The ticket of the NEXT item is taken by the I/O wave near the end of the current one, and the flags
+    // that item will look at first (left neighbour finished? guidance of its strip complete?) are read
+    // right behind it: no workgroup-wide stall on an atomic or a flag at item boundaries.
+    if (tid == 0) s_item = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool nx_valid = false, nx_pd = false, nx_gd = false;     // I/O wave: prefetched state of the next item
     for (;;) {
-        if (tid == 0) s_item = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const int item = s_item;
         if (item >= A.nitems) break;
-        const int k = item / nsv;
-        const int sv = item - k * nsv;
-        const int view = MODE == GUID ? sv : sv / A.nslices;
-        const int slice = MODE == GUID ? 0 : sv - view * A.nslices;
+        // FUSED launches hand out the guidance items (view, strip) first: an aggregation item only ever
+        // waits for items with smaller tickets (its left neighbour, the guidance item of its strip)
+        const bool agg = MODE == AGG || (MODE == FUSED && item >= A.nguid);
+        const int nsv_i = agg ? nsv : (MODE == FUSED ? A.nviews : nsv);   // slice-views of this item's kind
+        const int item_i = (MODE == FUSED && agg) ? item - A.nguid : item;
+        const int k = item_i / nsv_i;
+        const int sv = item_i - k * nsv_i;
+        const int view = agg ? sv / A.nslices : sv;
+        const int slice = agg ? sv - view * A.nslices : 0;
+        f2* const hand_i = agg ? A.hand : (MODE == FUSED ? A.ghand : A.hand);
+        unsigned* const flags_i = agg ? A.flags : (MODE == FUSED ? A.gflags : A.flags);
         const View& V = A.v[view];
         const int xs = k * OW;
         const int cs1 = xs - R - 1;             // image column of ring-1 column 0
@@ -322,11 +337,16 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             // flag = t.  Inputs for step t are loaded at step t - 2 (needs the neighbour's flag >= t)
             // and moved to LDS at step t - 1, so neither direction exposes memory latency to the scans.
             // =====================================================================================
-            unsigned* const myflag = A.flags + (size_t)sv * K + k;
-            bool pred_done = !pred;
+            unsigned* const myflag = flags_i + (size_t)sv * K + k;
+            unsigned* const gready = MODE == FUSED ? A.gready + (size_t)view * K + k : nullptr;
+            bool gdone = nx_valid && nx_gd;      // guidance of this strip complete (FUSED aggregation items)
+            bool pred_done = !pred || (nx_valid && nx_pd);
+            nx_valid = false;
+            unsigned nx_tk = 0, nx_pf = 0, nx_gf = 0;   // next ticket / its neighbour's flag / its guidance flag
+            bool nx_haspred = false, nx_hasg = false;
             const size_t recs = (size_t)NB * REC_F2;      // float2 per (parity, slice-view)
-            const rsrc_t r_in = mk_rsrc(A.hand + ((size_t)((k - 1) & 1) * nsv + sv) * recs, recs * 8);
-            const rsrc_t r_out = mk_rsrc(A.hand + ((size_t)(k & 1) * nsv + sv) * recs, recs * 8);
+            const rsrc_t r_in = mk_rsrc(hand_i + ((size_t)((k - 1) & 1) * nsv_i + sv) * recs, recs * 8);
+            const rsrc_t r_out = mk_rsrc(hand_i + ((size_t)(k & 1) * nsv_i + sv) * recs, recs * 8);
             f4 hreg[NHU];
             f4 c1reg = {0, 0, 0, 0}, c2reg = {0, 0, 0, 0};
             int hlo = 0, hhi = 0;        // a/b rows of the halo values in hreg
@@ -362,7 +382,33 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 // previous step: the wait is (nearly) free
                 drain_vmem();
                 if (succ && lane == 0 && i >= -1) flag_store(myflag, (unsigned)(2 * i + 2));
-                if (MODE == AGG && pred) {
+                // guidance item: the box waves stored band i-1 of mean_I / 1/(var+eps) in step A(i-1) (sc1) and
+                // drained at the end of step B(i-1), a step later -> publish it
+                if (MODE == FUSED && !agg && lane == 0 && i - 1 >= 0 && i - 1 < NB)
+                    flag_store(gready, i - 1 == NB - 1 ? FLAG_DONE : (unsigned)i);
+                if (i == NB - 1) {                         // 1. ticket of the next item (returns one step later)
+                    if (lane == 0)
+                        nx_tk = __hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (i == NB) {                      // 2. publish it; read the flags it will need first
+                    const unsigned t = __builtin_amdgcn_readfirstlane(nx_tk);
+                    if (lane == 0) s_next = (int)t;
+                    if (t < (unsigned)A.nitems) {
+                        const bool nagg = MODE == AGG || (MODE == FUSED && (int)t >= A.nguid);
+                        const int nn = nagg ? nsv : (MODE == FUSED ? A.nviews : nsv);
+                        const int ti = (MODE == FUSED && nagg) ? (int)t - A.nguid : (int)t;
+                        const int nk = ti / nn, nsvi = ti - nk * nn;
+                        unsigned* const nfl = (nagg ? A.flags : (MODE == FUSED ? A.gflags : A.flags)) + (size_t)nsvi * K + nk;
+                        nx_haspred = nk > 0;
+                        if (nx_haspred) nx_pf = flag_load(nfl - 1);
+                        nx_hasg = MODE == FUSED && nagg;
+                        if (nx_hasg) nx_gf = flag_load(A.gready + (size_t)(nsvi / A.nslices) * K + nk);
+                    }
+                } else if (i == NB + 1) {                  // 3. both loads are back (drain above)
+                    nx_valid = true;
+                    nx_pd = !nx_haspred || __builtin_amdgcn_readfirstlane(nx_pf) == FLAG_DONE;
+                    nx_gd = nx_hasg && __builtin_amdgcn_readfirstlane(nx_gf) == FLAG_DONE;
+                }
+                if (MODE != GUID && agg && pred) {
                     // halo columns + stage-2 carries loaded at B(i-1) -> ring 2 / staging
 #pragma unroll
                     for (int e = 0; e < NHU; ++e) {
@@ -377,10 +423,26 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     }
                     if (lane < BH / 2) *(f4*)&cin[1][2 * lane] = c2reg;
                 }
-                if (MODE == AGG && succ && i - 1 >= 0 && i - 1 < NB) {
+                if (MODE != GUID && agg && succ && i - 1 >= 0 && i - 1 < NB) {
                     // stage-2 carries of band i-1 (row scan at B(i-1)) -> global
                     if (lane < BH / 2)
                         st16_sc1(r_out, (unsigned)(((i - 1) * REC_F2 + BH) * 8 + lane * 16), *(const f4*)&cout[1][2 * lane]);
+                }
+                if (MODE == FUSED && agg && !gdone && i + 1 >= 0 && i + 1 < NB) {
+                    // the box waves load mean_I / 1/(var+eps) of the a/b rows of band i+1 in step B(i):
+                    // the guidance item of this strip must have stored (and drained) them
+                    const unsigned need = (unsigned)(i + 2);
+                    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+                    for (;;) {
+                        const unsigned f = flag_load(gready);
+                        if (f >= need) { gdone = f == FLAG_DONE; break; }
+                        __builtin_amdgcn_s_sleep(4);
+                        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull || flag_load(A.status) != 0u) {
+                            flag_store(A.status, 1u + (unsigned)item);
+                            gdone = true;
+                            break;
+                        }
+                    }
                 }
                 if (pred && i + 2 < NB) {
                     // stage-1 carries for the row scan of band i+2 at A(i+1): load now
@@ -393,12 +455,13 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 // ------------------------------ step B(i), t = 2i + 5 ---------------------------
                 drain_vmem();
                 if (succ && lane == 0 && i >= -1) flag_store(myflag, (unsigned)(2 * i + 3));
+
                 if (pred && lane < BH / 2) *(f4*)&cin[0][2 * lane] = c1reg;
                 // stage-1 carries of band i+1 (row scan at A(i)) and halo columns of band i -> global
                 if (succ) {
                     if (i + 1 >= 0 && i + 1 < NB && lane < BH / 2)
                         st16_sc1(r_out, (unsigned)((i + 1) * REC_F2 * 8 + lane * 16), *(const f4*)&cout[0][2 * lane]);
-                    if (MODE == AGG && i >= 0 && i < NB) {
+                    if (MODE != GUID && agg && i >= 0 && i < NB) {
                         f4 hv[NHU];
 #pragma unroll
                         for (int e = 0; e < NHU; ++e) {          // all LDS reads first, then the stores
@@ -414,7 +477,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     }
                 }
                 // stage-2 carries + halo columns of band i+1 (used at B(i+1) / A(i+1)): load now
-                if (MODE == AGG && pred) {
+                if (MODE != GUID && agg && pred) {
                     rows2(i + 1, lo, hi);
                     hlo = lo; hhi = hi;
                     if (lo < hi && i + 1 < NB) {
@@ -442,7 +505,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             f2 S1 = ident, S2 = ident, S1b = ident, S2b = ident;
             for (int i = -2; i <= NB + 1; ++i) {
                 int lo, hi;
-                if (MODE == AGG) {
+                if (MODE != GUID && agg) {
                     rows2(i - 1, lo, hi);                  // A(i): stage 2, band i-1
                     if (i - 1 == 0) { S2 = ident; S2b = ident; }
                     colscan(ring2, lane, lo, hi, S2);
@@ -555,7 +618,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 V3_STAMP(0);
                 wg_barrier();
                 V3_STAMP(1);
-                if (MODE == AGG) {                         // B(i): stage 2, band i
+                if (MODE != GUID && agg) {                         // B(i): stage 2, band i
                     rows2(i, lo, hi);
                     rowscan(ring2, 1, lo, hi, jlo2, jhi2);
                 }
@@ -672,7 +735,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 // loads consumed in step B(i): guidance image of the q rows, stage-1 inputs of band i+2
                 const int be = i + 2;
                 const bool ev = be < NB && be * BH < h;
-                if (MODE == AGG) {
+                if (MODE != GUID && agg) {
                     rows3(i - 1, ylo, yhi);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -687,9 +750,9 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                         const int y = e < 2 ? min(be * BH + 2 * wb + e, h - 1) : min(be * BH + 2 * wb + rsel, h - 1);
                         const char* b1 = (const char*)(FG1 + (unsigned)y * fgw);
                         ua[e] = *(const uint32_t*)(b1 + e_v1[e]);
-                        if (MODE == AGG && SRC == SRC_IMG)
+                        if (MODE != GUID && agg && SRC == SRC_IMG)
                             ub[e] = *(const uint32_t*)((const char*)(FG2 + (unsigned)y * fgw) + e_v2[e]);
-                        if (MODE == AGG && SRC == SRC_COST)
+                        if (MODE != GUID && agg && SRC == SRC_COST)
                             ub[e] = *(const uint32_t*)((const char*)(V.cost + ((size_t)slice * h + y) * w) + e_v2[e]);
                     }
                 }
@@ -710,14 +773,19 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const int y = yy[t];
-                        if (MODE == GUID) {
+                        if (MODE != AGG && !agg) {
                             float mm = m[t].x * m[t].x;    // pixelMultOnGPU(mean, mean) guidedFilter.cu:112
                             float var = m[t].y - mm;       // pixelSousOnGPU :121
                             float c = (float)(1.0f / ((double)var + A.eps));   // :350
                             if (g1.xin && ok[t]) {
                                 const unsigned o = (unsigned)y * (unsigned)w + (unsigned)g1.xc;
-                                V.gmean[o] = m[t].x;
-                                V.gcinv[o] = c;
+                                if (MODE == FUSED) {       // read by other workgroups of this launch
+                                    __hip_atomic_store((gf32*)(V.gmean + o), m[t].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                    __hip_atomic_store((gf32*)(V.gcinv + o), c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                } else {
+                                    V.gmean[o] = m[t].x;
+                                    V.gcinv[o] = c;
+                                }
                                 if (V.mean_u8) {           // flToChOnGPU :451-458
                                     int ci8 = (int)m[t].x;
                                     V.mean_u8[o] = (ci8 > 255) ? 255 : (uint8_t)ci8;
@@ -741,18 +809,24 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 V3_STAMP(1);
                 // ------------------------------ step B(i) -----------------------------------------
                 // loads consumed in step A(i+1): guidance statistics of the a/b rows of band i+1
-                if (MODE == AGG && xs < w) {
+                if (MODE != GUID && agg && xs < w) {
                     rows2(i + 1, ylo, yhi);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const int y = ylo + 2 * wb + t;
                         if (y < yhi) {
-                            ga[t] = V.mean[(unsigned)y * (unsigned)w + (unsigned)g1.xc];
-                            gb[t] = V.cinv[(unsigned)y * (unsigned)w + (unsigned)g1.xc];
+                            const unsigned o = (unsigned)y * (unsigned)w + (unsigned)g1.xc;
+                            if (MODE == FUSED) {           // written by a guidance item of this launch
+                                ga[t] = __hip_atomic_load((gf32*)(V.mean + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                gb[t] = __hip_atomic_load((gf32*)(V.cinv + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            } else {
+                                ga[t] = V.mean[o];
+                                gb[t] = V.cinv[o];
+                            }
                         }
                     }
                 }
-                if (MODE == AGG) {                         // box means of stage 2 -> q of band i-1
+                if (MODE != GUID && agg) {                         // box means of stage 2 -> q of band i-1
                     rows3(i - 1, ylo, yhi);
                     if (ylo + 2 * wb < yhi) {
                         float* __restrict__ qp = V.q + (size_t)slice * h * w;
@@ -779,7 +853,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     for (int e = 0; e < NE; ++e) {
                         const fg_t q1 = __builtin_bit_cast(fg_t, ua[e]);
                         f2 v;
-                        if (MODE == GUID) {
+                        if (MODE != AGG && !agg) {
                             v.x = (float)q1.x;            // chToFlOnGPU guidedFilter.cu:442-449
                             v.y = v.x * v.x;              // pixelMultOnGPU(d_im, d_im) :111
                         } else if (SRC == SRC_IMG) {
@@ -791,12 +865,16 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                         if (e < 2 || e2_ok) rb[e_ro[e]] = v;
                     }
                 }
+                // guidance item of a FUSED launch: every storing wave drains its (sc1) stores of step A, a
+                // step old by now, before the barrier behind which the I/O wave publishes the band
+                if (MODE == FUSED && !agg) drain_vmem();
                 V3_STAMP(2);
                 wg_barrier();
                 V3_STAMP(3);
             }
         }
         __syncthreads();
+        if (tid == 0) s_item = s_next;
     }
 }
 
@@ -874,7 +952,7 @@ size_t v3_workspace_bytes(int w, int h, int nslices) {
     b += 2 * align_up(L.fg * 4, 256);                               // both image planes (single-view calls too)
     b += 2 * align_up(L.plane * 4, 256);                            // mean_I, 1/(var+eps)
     b += align_up(L.sv_hand * 4, 256);                              // guidance hand-off records
-    b += v3_flag_bytes(L, 2);                                       // guidance control block (shared)
+    b += v3_flag_bytes(L, 4);                                       // guidance control block (shared)
     b += (size_t)nslices * align_up(L.plane * 4, 256);              // q
     b += align_up((size_t)nslices * L.sv_hand * 4, 256);
     b += v3_flag_bytes(L, 2 * nslices);                             // control block (shared by both views)
@@ -941,7 +1019,7 @@ int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     for (int i = 0; i < 2; ++i) FG[i] = (v3::fg_t*)carve(L.fg * 4);
     for (int v = 0; v < nviews; ++v) { meanI[v] = (float*)carve(L.plane * 4); cinv[v] = (float*)carve(L.plane * 4); }
     v3::f2* ghand = (v3::f2*)carve((size_t)nviews * L.sv_hand * 4);
-    char* gctrl = (char*)carve(v3_flag_bytes(L, nviews));
+    char* gctrl = (char*)carve(v3_flag_bytes(L, 2 * nviews));   // ticket + hand-off flags + ready counters
     const int total = s_end - s_begin;
     // per slice-view: q plane (unless the caller's volume is written directly) + scratch + flags
     const bool own_q = !(d_agg && d_agg[0]);
@@ -982,24 +1060,30 @@ int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         a0.v[v].FG1 = FG[v]; a0.v[v].FG2 = FG[v ^ 1];
         a0.v[v].mean = meanI[v]; a0.v[v].cinv = cinv[v];
     }
-    // ---- guidance statistics (single-stage walker, one slice-view per view) --------------------
-    {
-        v3::Args g = a0;
-        for (int v = 0; v < nviews; ++v) {
-            g.v[v].gmean = meanI[v]; g.v[v].gcinv = cinv[v];
-            g.v[v].mean_u8 = d_mean_u8 ? d_mean_u8[v] : nullptr;
-        }
-        g.nslices = 1; g.nsv = nviews; g.nitems = nviews * L.K;
+    // ---- guidance statistics: (view, strip) items of the single-stage walker.  They ride in the first
+    //      aggregation launch (FUSED: handed out first, the aggregation items of a strip follow its
+    //      guidance item band by band), or run alone when this call has no slices to aggregate.
+    v3::Args g = a0;
+    for (int v = 0; v < nviews; ++v) {
+        g.v[v].gmean = meanI[v]; g.v[v].gcinv = cinv[v];
+        g.v[v].mean_u8 = d_mean_u8 ? d_mean_u8[v] : nullptr;
+    }
+    unsigned* const gflags = (unsigned*)(gctrl + V3_CTRL_BYTES);
+    unsigned* const gready = gflags + (size_t)nviews * L.K;
+    SMX_HIP(hipMemsetAsync(gctrl, 0, v3_flag_bytes(L, 2 * nviews), st));
+    ++nl;
+    if (total <= 0) {
+        g.nslices = 1; g.nsv = nviews; g.nitems = nviews * L.K; g.nviews = nviews;
         g.hand = ghand;
         g.ticket = (unsigned*)gctrl; g.status = status;
-        g.flags = (unsigned*)(gctrl + V3_CTRL_BYTES);
-        SMX_HIP(hipMemsetAsync(gctrl, 0, v3_flag_bytes(L, nviews), st));
+        g.flags = gflags;
         if ((rc = launch_walk3<v3::GUID, v3::SRC_IMG>(g, st))) return rc;
-        nl += 2;
+        ++nl;
     }
+    bool first = true;
     for (int s0 = s_begin; s0 < s_end; s0 += chunk) {
         const int cnt = (s_end - s0) < chunk ? (s_end - s0) : chunk;
-        v3::Args a = a0;
+        v3::Args a = first ? g : a0;      // the first launch also carries the guidance outputs
         v3::WtaArgs wa;
         for (int v = 0; v < 2; ++v) {
             const int vv = v < nviews ? v : 0;
@@ -1012,14 +1096,18 @@ int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             wa.q[v] = qv;
             wa.keys[v] = d_keys[vv];
         }
-        a.nslices = cnt; a.nsv = cnt * nviews; a.nitems = a.nsv * L.K;
-        a.hand = hand;
+        a.nslices = cnt; a.nsv = cnt * nviews; a.nviews = nviews;
+        a.nguid = first ? nviews * L.K : 0;
+        a.nitems = a.nguid + a.nsv * L.K;
+        a.hand = hand; a.ghand = ghand;
         a.ticket = (unsigned*)ctrl; a.status = status;
         a.flags = (unsigned*)(ctrl + V3_CTRL_BYTES);
+        a.gflags = gflags; a.gready = gready;
         SMX_HIP(hipMemsetAsync(ctrl, 0, v3_flag_bytes(L, a.nsv), st));
-        if (use_cost) rc = launch_walk3<v3::AGG, v3::SRC_COST>(a, st);
-        else rc = launch_walk3<v3::AGG, v3::SRC_IMG>(a, st);
+        if (first) rc = use_cost ? launch_walk3<v3::FUSED, v3::SRC_COST>(a, st) : launch_walk3<v3::FUSED, v3::SRC_IMG>(a, st);
+        else rc = use_cost ? launch_walk3<v3::AGG, v3::SRC_COST>(a, st) : launch_walk3<v3::AGG, v3::SRC_IMG>(a, st);
         if (rc) return rc;
+        first = false;
         hipLaunchKernelGGL(v3::k_v3_wta, dim3(cdivu3((int64_t)L.plane, 256), nviews), dim3(256), 0, st, wa,
                            L.plane, cnt, s0);
         SMX_HIP(hipGetLastError());
