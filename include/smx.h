@@ -13,9 +13,13 @@
  *                      reference-signature C++ functions in stereo_matching_cuda_amd/host/
  *                      (costVolume.cuh, guidedFilter.cuh, ...) are one-line forwards.
  *   smx_dev_<stage>()  device pointers, asynchronous on a caller-supplied hipStream_t
- *                      (passed as void*), caller-supplied workspace; no allocation, no
- *                      synchronisation inside -> capturable in a hipGraph.  Used by the
- *                      fused pair path, the benchmark and the multi-GPU (D-sharded) driver.
+ *                      (passed as void*) of the CURRENT device, caller-supplied workspace; no
+ *                      allocation, no synchronisation and no internal streams or events: a
+ *                      call is a fixed sequence of kernel launches and small memsets on
+ *                      `stream`, so a pair step can be captured into a hipGraph and replayed
+ *                      (tests/test_gpu_parity.py::test_pair_step_is_capturable_in_a_hip_graph).
+ *                      Used by the pair path, the benchmark and the multi-GPU (D-sharded)
+ *                      drivers (sharded.py; include/smx_rccl.h).
  *
  * All functions return 0 on success or a negative code (SMX_E_*); smx_last_error() gives
  * the message of the last failure on the calling thread.  There is no CPU fallback: without
@@ -91,7 +95,8 @@ int smx_compute_guided_filter(const smx_params* p, const uint8_t* i, const float
 int smx_detect_occlusion(const smx_params* p, float* disparityLeft, const float* disparityRight,
                          int dOcclusion, int w, int h);
 
-/* occlusion.cuh:14  void fill_occlusion(float* disparity, w, h, vMin) ; in place. */
+/* occlusion.cuh:14  void fill_occlusion(float* disparity, w, h, vMin) ; in place.
+ * One wave per row with the row staged in LDS: w <= 16384 (SMX_E_ARG above that). */
 int smx_fill_occlusion(float* disparity, int w, int h, float vMin);
 
 /* filter.cuh:12  void filter(image, width, height, mean, var, cuda)   (dead code in the reference:
@@ -133,7 +138,10 @@ int smx_dev_cost_volume(const smx_params* p, const uint8_t* d_i1, const uint8_t*
 /* nplanes independent w*h planes, in place allowed (d_in == d_out). */
 int smx_dev_integral(const float* d_in, float* d_out, int w, int h, int nplanes, void* stream);
 
-/* Bytes of workspace smx_dev_aggregate_wta needs for `nslices` slices in flight. */
+/* Bytes of workspace smx_dev_aggregate_wta needs for `nslices` slices of ONE view in flight (the pair
+ * call needs twice that): image / guidance planes, per slice one aggregated plane plus the strip
+ * hand-off records, control words.  The first 256 bytes hold the call's status word
+ * (smx_dev_agg_status).  Fewer slices in flight than s_end - s_begin only means more launches. */
 size_t smx_agg_workspace_bytes(int w, int h, int nslices);
 
 /* Guided-filter aggregation + running winner-take-all over slices [s_begin, s_end) of ONE
@@ -154,8 +162,7 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
                           size_t workspace_bytes, void* stream);
 
 /* Both views of a stereo pair in one call (main.cu:133-134 back to back): every kernel launch
- * covers the left and the right volume, which halves the launch count and hides the latency-bound
- * prepasses.  View 0 = left (guide d_left, labels dminl + s), view 1 = right (guide d_right, labels
+ * covers the left and the right volume.  View 0 = left (guide d_left, labels dminl + s), view 1 = right (guide d_right, labels
  * dminr + s).  d_keys: 2*n keys (left then right); d_mean_u8: NULL or 2*n bytes; d_agg: NULL or two
  * volumes of (s_end - s_begin)*n floats.  Workspace: >= 2 * smx_agg_workspace_bytes(w, h, nslices). */
 int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const uint8_t* d_right,
@@ -164,10 +171,11 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
                                size_t workspace_bytes, void* stream);
 
 /* Synchronous health check of the last smx_dev_aggregate_wta[_pair] call that used d_workspace:
- * copies the call's status word back (implicit stream synchronisation of the null stream; call it
- * after synchronising the launch stream).  SMX_E_HIP if a workgroup of the fused kernel gave up
- * waiting for its left neighbour (the spins are bounded, 2 s), in which case the results are
- * invalid.  Not needed for correctness in normal operation. */
+ * copies the call's status word back (call it after synchronising the launch stream).  SMX_E_HIP if
+ * a workgroup of the fused kernel gave up waiting for another one (its left neighbour strip or the
+ * guidance of its strip; the spins are bounded, 2 s), in which case the results are invalid.  The
+ * waits cannot deadlock (every wait is for a work item with a smaller ticket), so this only fires
+ * if the GPU is taken away mid-launch; the host-pointer wrappers call it for you. */
 int smx_dev_agg_status(const void* d_workspace);
 
 /* Aggregation implementation: 0 = auto (the fused single-kernel aggregation when radius <= 9,
