@@ -3,8 +3,8 @@
 // never leaving the CU.  Reference: guidedFilter.cu:58-238, costVolume.cu:163-190, integral.cu:78-131.
 //
 // Work item = (slice-view sv, strip k): a column strip of OW = 64 output columns, walked top -> bottom
-// in bands of BH = 32 rows by one 1024-thread workgroup (one per CU, 132 KB of LDS).  Two LDS rings of
-// 96 rows x 83 columns of float2 hold the integral images of stage 1 (p, I*p) and stage 2 (a, b): a
+// in bands of BH = 26 rows by one 1024-thread workgroup (one per CU, ~112 KB of LDS).  Two LDS rings of
+// 78 rows x 83 columns of float2 hold the integral images of stage 1 (p, I*p) and stage 2 (a, b): a
 // box mean needs the 2R+2 most recent rows, the third band of the ring is the one being produced.
 //
 // Exactness: every prefix sum keeps the reference's order (sequential left -> right in a row, then
@@ -16,18 +16,21 @@
 //
 // Schedule (software pipeline over bands, two workgroup barriers per band):
 //   step A(i):  wave 0: row scan stage 1 of band i+1 | wave 1: column scan stage 2 of band i-1 |
-//               waves 2-15: box means of stage 1 -> a_k, b_k of band i into ring 2 (+ halo columns)
+//               wave 2: hand-off I/O | waves 3-15: box means of stage 1 -> a_k, b_k of band i into ring 2
 //   step B(i):  wave 0: row scan stage 2 of band i   | wave 1: column scan stage 1 of band i+1 |
-//               waves 2-15: box means of stage 2 -> q of band i-1 to HBM, then cost of band i+2 -> ring 1
-// Lane mapping: LANE = ROW in the row scans, LANE = COLUMN everywhere else, so every global access is
-// a row-major coalesced run and the aggregated volume comes out in the reference's [z][y][x] layout.
+//               wave 2: hand-off I/O | waves 3-15: box means of stage 2 -> q of band i-1 to HBM, then the
+//               cost of band i+2 -> ring 1
+// Lane mapping: in the row scans lanes 0..25 / 32..57 are the rows of the band for the first / second
+// component; LANE = COLUMN everywhere else, so every global access is a row-major coalesced run and the
+// aggregated volume comes out in the reference's [z][y][x] layout.
 //
 // Items are handed out by a ticket counter in strip-major order, so the left neighbour of an item
 // always holds an earlier ticket (it is running or done: no deadlock whatever the dispatch order).
 // The hand-off is the sc1 form of the guide (write-through stores, drained, one flag per item that
-// counts finished bands; sc1 loads behind a relaxed poll + workgroup barrier; no acquire fence).
+// counts finished steps; sc1 loads behind a relaxed poll + workgroup barrier; no acquire fence).
 //
-// MODE GUID runs stage 1 alone on (I, I*I) and writes mean_I and 1/(var_I + eps) (guidedFilter.cu:58-123).
+// MODE GUID runs stage 1 alone on (I, I*I) and writes mean_I and 1/(var_I + eps) (guidedFilter.cu:58-123);
+// MODE FUSED hands those guidance items out first in the same launch as the aggregation items.
 // SRC_COST reads p from a materialised [z][y][x] cost volume (the reference's calling convention,
 // guidedFilter.cu:198) instead of building it from the two images.
 //
@@ -44,8 +47,8 @@ constexpr int OW = 64;                  // output columns per strip = one wave
 constexpr int RMAX = 9;                 // largest supported box radius
 constexpr int HWMAX = 2 * RMAX + 1;     // halo / overlap columns
 constexpr int TWMAX = OW + HWMAX;       // ring columns in use (83 at R = 9)
-constexpr int PITCH = 86;               // float2 per ring row: even (16-B aligned column pairs) and
-                                        // PITCH/2 odd (LANE = ROW 16-B accesses hit distinct banks)
+constexpr int PITCH = 85;               // float2 per ring row: odd, so the LANE = ROW dword accesses of the row
+                                        // scan (row stride 2 PITCH dwords) hit distinct banks
 constexpr int NT = 1024;
 constexpr int NWAVE = NT / 64;
 constexpr int W_R = 0;                  // row-scan wave
@@ -56,6 +59,7 @@ constexpr int NWB = NWAVE - W_B0;       // 13
 constexpr int BH = 2 * NWB;             // band height: every box wave owns two rows of a band
 constexpr int RR = 3 * BH;              // ring rows
 static_assert(RR >= 2 * BH + 2 * RMAX + 2, "ring too small for the two-step pipeline");
+static_assert(RR == 3 * BH, "band i starts at ring row (i mod 3) * BH");
 
 enum Mode { GUID = 0, AGG = 1, FUSED = 2 };   // FUSED: guidance items + aggregation items in one launch
 enum Src { SRC_IMG = 0, SRC_COST = 1 };
@@ -218,6 +222,11 @@ __device__ unsigned long long g_stamps[NWAVE * STAMP_SLOTS];
 #else
 #define V3_STAMP(n) ((void)0)
 #endif
+// Diagnostic build only (-DSMX_V3_ITEMLOG, tools/v3_itemlog.sh): start / end clock and CU of every work item.
+#ifdef SMX_V3_ITEMLOG
+constexpr int ITEMLOG_MAX = 1 << 16;
+__device__ unsigned long long g_itemlog[3 * ITEMLOG_MAX];
+#endif
 // Workgroup barrier that orders LDS only: __syncthreads() would also wait for every outstanding
 // global load and store (vmcnt(0)), which is exactly the latency the cross-step prefetches hide.
 __device__ __forceinline__ void wg_barrier() {
@@ -244,6 +253,7 @@ constexpr int REC_F2 = 2 * BH + BH * HP;          // float2 per band record
 constexpr int NHU = (BH * HP / 2 + 63) / 64;      // 16-byte halo units per lane of the I/O wave
 static_assert(BH % 2 == 0 && HP % 2 == 0 && (REC_F2 % 2) == 0, "16-byte hand-off units");
 static_assert(BH == 2 * NWB, "every box wave owns two rows of a band");
+static_assert(BH <= 32, "the row scan maps rows to the lanes of half a wave");
 
 template <int MODE, int SRC>
 __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
@@ -278,6 +288,12 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
         __syncthreads();
         const int item = s_item;
         if (item >= A.nitems) break;
+#ifdef SMX_V3_ITEMLOG
+        if (tid == 0 && item < ITEMLOG_MAX) {
+            g_itemlog[3 * item] = __builtin_amdgcn_s_memrealtime();
+            g_itemlog[3 * item + 2] = blockIdx.x;
+        }
+#endif
         // FUSED launches hand out the guidance items (view, strip) first: an aggregation item only ever
         // waits for items with smaller tickets (its left neighbour, the guidance item of its strip)
         const bool agg = MODE == AGG || (MODE == FUSED && item >= A.nguid);
@@ -325,6 +341,42 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 n -= run;
                 rr = 0;
             }
+        };
+
+        // both column groups of a band (ring columns lane and lane + 64).  A full band that does not wrap in
+        // the ring (the common case) is straight-line code in batches of 8 rows: the reads of the next batch
+        // are issued before the adds and writes of the current one, so the LDS latency is exposed once per
+        // column group instead of once per batch (and once per row in the remainder)
+        auto colscan_band = [&](f2* ring, int lo, int hi, f2& S, f2& Sb, bool ccol) {
+            const int rr = lo % RR;
+            if (hi - lo == BH && rr + BH <= RR) {
+                constexpr int CB = 8, NCB = (BH + CB - 1) / CB;
+                auto group = [&](f2* p, f2& acc) {
+                    f2 v[2][CB];
+#pragma unroll
+                    for (int t = 0; t < CB; ++t) v[0][t] = p[t * PITCH];
+#pragma unroll
+                    for (int b = 0; b < NCB; ++b) {
+                        if (b + 1 < NCB) {
+#pragma unroll
+                            for (int t = 0; t < CB; ++t)
+                                if ((b + 1) * CB + t < BH) v[(b + 1) & 1][t] = p[((b + 1) * CB + t) * PITCH];
+                        }
+#pragma unroll
+                        for (int t = 0; t < CB; ++t)
+                            if (b * CB + t < BH) {
+                                acc = v[b & 1][t] + acc;
+                                p[(b * CB + t) * PITCH] = acc;
+                            }
+                    }
+                };
+                f2* const p = ring + rr * PITCH + lane;
+                group(p, S);
+                if (ccol) group(p + 64, Sb);
+                return;
+            }
+            colscan(ring, lane, lo, hi, S);
+            if (ccol) colscan(ring, lane + 64, lo, hi, Sb);
         };
 
         if (wave == W_IO) {
@@ -508,87 +560,75 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 if (MODE != GUID && agg) {
                     rows2(i - 1, lo, hi);                  // A(i): stage 2, band i-1
                     if (i - 1 == 0) { S2 = ident; S2b = ident; }
-                    colscan(ring2, lane, lo, hi, S2);
-                    if (ccol) colscan(ring2, lane + 64, lo, hi, S2b);
+                    colscan_band(ring2, lo, hi, S2, S2b, ccol);
                 }
                 V3_STAMP(0);
                 wg_barrier();
                 V3_STAMP(1);
                 rows1(i + 1, lo, hi);                      // B(i): stage 1, band i+1
                 if (i + 1 == 0) { S1 = ident; S1b = ident; }
-                colscan(ring1, lane, lo, hi, S1);
-                if (ccol) colscan(ring1, lane + 64, lo, hi, S1b);
+                colscan_band(ring1, lo, hi, S1, S1b, ccol);
                 V3_STAMP(2);
                 wg_barrier();
                 V3_STAMP(3);
             }
         } else if (wave == W_R) {
             // =====================================================================================
-            // row-scan wave (LANE = ROW): 16-byte LDS accesses (two columns each), the reads of the
-            // next 8 columns are issued before the adds of the current 8
+            // row-scan wave: lanes 0..25 carry the first component (p or a) of rows 0..25 of the band,
+            // lanes 32..57 the second one (I*p or b) of the same rows -- the cost of an LDS write grows with
+            // the dwords per lane (ds_write_b64 14, ds_write_b128 27 cycles of issue), not with the active
+            // lanes, so one dword per lane and column halves the dominant term of the dependent chain.
+            // Reads run one batch of 8 columns ahead of the adds.
             // =====================================================================================
             const int jlo1 = max(0, -cs1), jhi1 = min(TW, w - cs1);   // ring-1 columns inside the image
             const int jlo2 = max(0, -cs2), jhi2 = min(TW, w - cs2);
+            const int srow = lane & 31, comp = lane >> 5;
             auto rowscan = [&](f2* ring, int st, int ylo, int yhi, int jlo, int jhi) {
-                if (lane >= yhi - ylo || jhi <= jlo) return;
-                const int y = ylo + lane;
-                f2 acc = pred ? cin[st][lane] : ident;
-                f2* row = ring + (y % RR) * PITCH;
-                int j = jlo;
+                if (srow >= yhi - ylo || jhi <= jlo) return;
+                const int y = ylo + srow;
+                float acc = pred ? ((const float*)&cin[st][srow])[comp] : -0.0f;
+                float* row = (float*)(ring + (y % RR) * PITCH) + comp;   // column c of this component: row[2 c]
                 if (jlo == 0 && jhi == TWMAX) {
                     // the common case (a strip inside the image at radius 9): 83 columns, fully unrolled so
-                    // that every LDS wait is a counted one -- the reads of the next eight columns are in
-                    // flight while the eight dependent adds of the current batch issue
+                    // that every LDS wait is a counted one
                     constexpr int NBATCH = TWMAX / 8;                  // 10 batches of 8 + 3 columns
-                    f4 v[2][4];
+                    float v[2][8];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) v[0][t] = *(const f4*)(row + 2 * t);
+                    for (int t = 0; t < 8; ++t) v[0][t] = row[2 * t];
 #pragma unroll
                     for (int bt = 0; bt < NBATCH; ++bt) {
                         if (bt + 1 < NBATCH) {
 #pragma unroll
-                            for (int t = 0; t < 4; ++t) v[(bt + 1) & 1][t] = *(const f4*)(row + 8 * (bt + 1) + 2 * t);
+                            for (int t = 0; t < 8; ++t) v[(bt + 1) & 1][t] = row[2 * (8 * (bt + 1) + t)];
                         }
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const f4 x = v[bt & 1][t];
-                            const f2 s0 = lo2(x) + acc;
-                            const f2 s1 = hi2(x) + s0;
-                            acc = s1;
-                            const f4 o = {s0.x, s0.y, s1.x, s1.y};
-                            *(f4*)(row + 8 * bt + 2 * t) = o;
-                            if (8 * bt + 2 * t + 1 == OW - 1) cout[st][lane] = s1;
+                        for (int t = 0; t < 8; ++t) {
+                            acc = v[bt & 1][t] + acc;
+                            row[2 * (8 * bt + t)] = acc;
+                            if (8 * bt + t == OW - 1) ((float*)&cout[st][srow])[comp] = acc;
                         }
                     }
 #pragma unroll
                     for (int c = 8 * NBATCH; c < TWMAX; ++c) {
-                        acc = row[c] + acc;
-                        row[c] = acc;
+                        acc = row[2 * c] + acc;
+                        row[2 * c] = acc;
                     }
                     return;
                 }
-                if (j & 1) {
-                    acc = row[j] + acc;
-                    row[j] = acc;
-                    ++j;
-                }
-                // batches of 8 columns, ping-pong: the reads of the next batch are always issued (past
-                // the end they fetch bytes nobody uses: LDS reads cannot fault) so that the wait before
-                // the adds is a constant count and the scheduler keeps one batch of reads in flight
+                // general strip: batches of 8 columns, ping-pong; the reads of the next batch are always
+                // issued (past the end they fetch bytes nobody uses: LDS reads cannot fault)
+                int j = jlo;
                 const int nb8 = (jhi - j) >> 3;
-                f4 va[4], vb[4];
-                auto rd = [&](f4 (&v)[4], int c) {
+                float va[8], vb[8];
+                auto rd = [&](float (&v)[8], int c) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] = *(const f4*)(row + c + 2 * t);
+                    for (int t = 0; t < 8; ++t) v[t] = row[2 * (c + t)];
                 };
-                auto run = [&](const f4 (&v)[4], int c) {
+                auto run = [&](const float (&v)[8], int c) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const f2 s0 = lo2(v[t]) + acc;
-                        const f2 s1 = hi2(v[t]) + s0;
-                        acc = s1;
-                        const f4 o = {s0.x, s0.y, s1.x, s1.y};
-                        *(f4*)(row + c + 2 * t) = o;
+                    for (int t = 0; t < 8; ++t) {
+                        acc = v[t] + acc;
+                        row[2 * (c + t)] = acc;
                     }
                 };
                 if (nb8 > 0) rd(va, j);
@@ -605,11 +645,11 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     j += 8;
                 }
                 for (; j < jhi; ++j) {
-                    acc = row[j] + acc;
-                    row[j] = acc;
+                    acc = row[2 * j] + acc;
+                    row[2 * j] = acc;
                 }
                 // running row sum left of the next strip's first column
-                if (OW - 1 >= jlo && OW - 1 < jhi) cout[st][lane] = row[OW - 1];
+                if (OW - 1 >= jlo && OW - 1 < jhi) ((float*)&cout[st][srow])[comp] = row[2 * (OW - 1)];
             };
             for (int i = -2; i <= NB + 1; ++i) {
                 int lo, hi;
@@ -631,32 +671,59 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             // box / eval waves (LANE = COLUMN); wave wb owns rows 2 wb and 2 wb + 1 of every band
             // =====================================================================================
             const int d = V.d0 + slice;
-            const fg_t* __restrict__ FG1 = V.FG1;
-            const fg_t* __restrict__ FG2 = V.FG2;
-            const unsigned fgw = (unsigned)w + 2;
+            const unsigned fgw4 = ((unsigned)w + 2u) * 4u, w4 = (unsigned)w * 4u;
+            const unsigned pitch2 = SRC == SRC_IMG ? fgw4 : w4;      // row pitch of the second stage-1 input
+            // Every global access of these waves is a buffer instruction: per-lane byte offset fixed for the
+            // item + wave-uniform row offset in a scalar register (rows are wave-uniform here), no 64-bit
+            // address arithmetic.  A lane whose column lies outside the image carries the offset OOB, which is
+            // beyond every plane: its loads return 0 and its stores are dropped by the range check.
+            constexpr unsigned OOB = 0x80000000u;
+            const size_t plane = (size_t)h * w;
+            const rsrc_t r_fg1 = mk_rsrc(V.FG1, (size_t)h * fgw4);
+            const rsrc_t r_in2 = !agg ? r_fg1
+                               : SRC == SRC_IMG ? mk_rsrc(V.FG2, (size_t)h * fgw4)
+                                                : mk_rsrc(V.cost + (size_t)slice * plane, plane * 4);
+            const rsrc_t r_ga = mk_rsrc(agg ? V.mean : V.gmean, plane * 4);   // mean_I:       read (agg) / written (guidance)
+            const rsrc_t r_gb = mk_rsrc(agg ? V.cinv : V.gcinv, plane * 4);   // 1/(var+eps)
+            const rsrc_t r_q = agg ? mk_rsrc(V.q + (size_t)slice * plane, plane * 4)
+                                   : mk_rsrc(V.mean_u8, V.mean_u8 ? plane : 0);     // guidance: optional u8 mean image
+            constexpr int AUX_G = MODE == FUSED ? AUX_SC1 : 0;   // mean_I / 1/(var+eps) cross workgroups inside a FUSED launch
+            constexpr int AUX_NT = 2;
+
             // per-lane window geometry in x: fixed for the whole item
-            struct Geo { int jmax, jmin, xcw, xc; bool hx, xin; };
-            auto mkgeo = [&](int x, int cs) {
-                Geo g;
-                g.xin = x >= 0 && x < w;
-                g.xc = min(max(x, 0), w - 1);
-                const int xmax = min(w - 1, g.xc + R), xmn = g.xc - R - 1;
-                g.hx = xmn >= 0;
-                g.xcw = xmax - (g.hx ? xmn : -1);
-                g.jmax = min(max(xmax - cs, 0), TW - 1);
-                g.jmin = min(max(xmn - cs, 0), TW - 1);
-                return g;
-            };
-            const Geo g1 = mkgeo(xs + lane, cs1);
-            const Geo g2 = mkgeo(xs - R + lane, cs2);
+            struct Geo { int jmax, jmin, xcw; bool hx; };
+            unsigned vq, vg, vg8;                     // q / guidance-image column, a_k/b_k column (x4), the latter in bytes x1
+            Geo g1, g2;
+            {
+                auto mkgeo = [&](int x, int cs, unsigned& off4, unsigned& off1) {
+                    Geo g;
+                    const bool xin = x >= 0 && x < w;
+                    const int xc = min(max(x, 0), w - 1);
+                    const int xmax = min(w - 1, xc + R), xmn = xc - R - 1;
+                    g.hx = xmn >= 0;
+                    g.xcw = xmax - (g.hx ? xmn : -1);
+                    g.jmax = min(max(xmax - cs, 0), TW - 1);
+                    g.jmin = min(max(xmn - cs, 0), TW - 1);
+                    off4 = xin ? (unsigned)xc * 4u : OOB;
+                    off1 = xin ? (unsigned)xc : OOB;
+                    return g;
+                };
+                unsigned dummy;
+                g1 = mkgeo(xs + lane, cs1, vg, vg8);
+                g2 = mkgeo(xs - R + lane, cs2, vq, dummy);
+            }
             // all 64 windows of the strip unclipped in x: no selects, one area per row
             const bool xint1 = xs - R - 1 >= 0 && xs + OW - 1 + R <= w - 1;
             const bool xint2 = xs - 2 * R - 1 >= 0 && xs + OW - 1 <= w - 1;
+            const f2* const p1max = ring1 + g1.jmax;
+            const f2* const p1min = ring1 + g1.jmin;
+            const f2* const p2max = ring2 + g2.jmax;
+            const f2* const p2min = ring2 + g2.jmin;
             // box means of two rows (computeBoxFilterOnGPU guidedFilter.cu:305-318: S11 - S10 - S01 + S00
             // in that order, then a true division by the clipped window area).  Branch-free: all ten
             // LDS reads are issued before the first use; clipped taps are read from a valid dummy
             // address and dropped by a select; the exact-division fix-up is one rare branch at the end.
-            auto box2 = [&](const f2* ring, const Geo& g, bool xint, const int (&yy)[2], f2 (&m)[2]) {
+            auto box2 = [&](const f2* pmax, const f2* pmin, int xcw, bool hx, bool xint, const int (&yy)[2], f2 (&m)[2]) {
                 f2 s11[2], s10[2], s01[2], s00[2], val[2];
                 float area[2], ra[2];
                 bool hy[2];
@@ -666,11 +733,10 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     const int ymin = yy[t] - R - 1;
                     hy[t] = ymin >= 0;
                     const int ych = ymax - (hy[t] ? ymin : -1);
-                    const f2* r1 = ring + (ymax % RR) * PITCH;
-                    const f2* r0 = ring + ((hy[t] ? ymin : 0) % RR) * PITCH;
-                    s11[t] = r1[g.jmax]; s10[t] = r1[g.jmin];
-                    s01[t] = r0[g.jmax]; s00[t] = r0[g.jmin];
-                    const int ai = (xint ? HW : g.xcw) * ych;
+                    const int o1 = (ymax % RR) * PITCH, o0 = ((hy[t] ? ymin : 0) % RR) * PITCH;
+                    s11[t] = pmax[o1]; s10[t] = pmin[o1];
+                    s01[t] = pmax[o0]; s00[t] = pmin[o0];
+                    const int ai = (xint ? HW : xcw) * ych;
                     area[t] = (float)ai;
                     ra[t] = rcp_s[ai];
                 }
@@ -679,11 +745,11 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 for (int t = 0; t < 2; ++t) {
                     f2 v = s11[t];
                     f2 u = v - s10[t];
-                    v = (xint || g.hx) ? u : v;
+                    v = (xint || hx) ? u : v;
                     u = v - s01[t];
                     v = hy[t] ? u : v;
                     u = v + s00[t];
-                    v = (hy[t] && (xint || g.hx)) ? u : v;
+                    v = (hy[t] && (xint || hx)) ? u : v;
                     val[t] = v;
                     m[t].x = div_small_int(v.x, area[t], ra[t]);
                     m[t].y = div_small_int(v.y, area[t], ra[t]);
@@ -698,98 +764,216 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     }
                 }
             };
-            // stage-1 input cells of this lane, fixed for the item: rows 2wb, 2wb+1 at ring column
-            // `lane`, and row 2wb + (lane >> 5) at ring column 64 + (lane & 31).  Loads are clamped into
-            // the image instead of predicated: cells outside it are written but never accumulated.
-            constexpr int NE = 3;
-            unsigned e_v1[NE], e_v2[NE];     // byte offsets inside the row of this view / the partner
-            int e_ro[NE];                    // ring offset (float2) relative to the band's first row
+            // The same for a band whose windows are all unclipped (the strip is x-interior and every row of the
+            // band is y-interior and exists): no selects, one area, and the ring rows follow from the band's
+            // position in the ring (r1 = ring row of y + R) without any division.
+            const float area_full = (float)(HW * HW), ra_full = rcp_s[HW * HW];
+            auto box2_fast = [&](const f2* pmax, const f2* pmin, const int (&r1)[2], f2 (&m)[2]) {
+                f2 s11[2], s10[2], s01[2], s00[2], val[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    int r0 = r1[t] - HW;
+                    r0 = r0 < 0 ? r0 + RR : r0;
+                    s11[t] = pmax[r1[t] * PITCH]; s10[t] = pmin[r1[t] * PITCH];
+                    s01[t] = pmax[r0 * PITCH];    s00[t] = pmin[r0 * PITCH];
+                }
+                bool slow = false;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f2 v = s11[t] - s10[t];
+                    v = v - s01[t];
+                    v = v + s00[t];
+                    val[t] = v;
+                    m[t].x = div_small_int(v.x, area_full, ra_full);
+                    m[t].y = div_small_int(v.y, area_full, ra_full);
+                    slow = slow || div_needs_exact(v.x) || div_needs_exact(v.y);
+                }
+                if (__any(slow)) {
+                    asm volatile("; exact-division slow path");
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        m[t].x = 1.0f * val[t].x / area_full;
+                        m[t].y = 1.0f * val[t].y / area_full;
+                    }
+                }
+            };
+            // stage-1 input cells of this lane, fixed for the item: rows 2wb, 2wb+1 at ring column `lane`
+            // (cells 0, 1) and row 2wb + (lane >> 5) at ring column 64 + (lane & 31) (cell 2).  Columns are
+            // clamped into the image instead of predicated: cells outside it are written but never accumulated.
             const int rsel = lane >> 5;      // row of the third cell
             const bool e2_ok = (lane & 31) < HW;
-#pragma unroll
-            for (int e = 0; e < NE; ++e) {
-                const int j = e < 2 ? lane : 64 + (lane & 31);
-                const int r = e < 2 ? 2 * wb + e : 2 * wb + rsel;
-                const int c = min(max(cs1 + j, 0), w - 1);
-                e_ro[e] = r * PITCH + min(j, PITCH - 1);
-                e_v1[e] = (unsigned)(c + 1) * 4u;
-                if (SRC == SRC_IMG) {
-                    int xx = c + d;
-                    xx = xx < -1 ? -1 : (xx > w ? w : xx);   // sentinel columns
-                    e_v2[e] = (unsigned)(xx + 1) * 4u;
-                } else {
-                    e_v2[e] = (unsigned)c * 4u;
-                }
+            unsigned in1a, in1b, in2a, in2b;     // byte offsets inside a row: cells 0/1 and cell 2, first / second input
+            int ro_a, ro_b;                      // ring offsets (float2) relative to the band's first row
+            {
+                auto cell = [&](int j, unsigned& o1, unsigned& o2) {
+                    const int c = min(max(cs1 + j, 0), w - 1);
+                    o1 = (unsigned)(c + 1) * 4u;
+                    if (SRC == SRC_IMG) {
+                        int xx = c + d;
+                        xx = xx < -1 ? -1 : (xx > w ? w : xx);   // sentinel columns
+                        o2 = (unsigned)(xx + 1) * 4u;
+                    } else {
+                        o2 = (unsigned)c * 4u;
+                    }
+                };
+                cell(lane, in1a, in2a);
+                cell(64 + (lane & 31), in1b, in2b);
+                ro_a = 2 * wb * PITCH + lane;
+                ro_b = (2 * wb + rsel) * PITCH + min(64 + (lane & 31), PITCH - 1);
             }
-            uint32_t ua[NE], ub[NE];
-            float ga[2], gb[2];
-            uint32_t Iraw[2];     // raw (value, gradient) halves: converted at use, a step after the load
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { ga[t] = 0.0f; gb[t] = 0.0f; Iraw[t] = 0; }
-#pragma unroll
-            for (int e = 0; e < NE; ++e) { ua[e] = 0; ub[e] = 0; }
+            uint32_t ua[3] = {0, 0, 0}, ub[3] = {0, 0, 0};
+            float ga[2] = {0.0f, 0.0f}, gb[2] = {0.0f, 0.0f};
+            uint32_t Iraw[2] = {0, 0};     // raw (value, gradient) halves: converted at use, a step after the load
 
-            for (int i = -2; i <= NB + 1; ++i) {
+            int ph1 = 1;                     // i mod 3: position of band i in the three-band rings (i = -2 first)
+            for (int i = -2; i <= NB + 1; ++i, ph1 = ph1 == 2 ? 0 : ph1 + 1) {
                 int ylo, yhi;
+                const int ph2 = ph1 == 0 ? 2 : ph1 - 1;          // (i - 1) mod 3 = (i + 2) mod 3
+                if (MODE != GUID && agg && xint1 && xint2 && (i - 1) * BH >= 3 * R + 1 && (i + 3) * BH <= h) {
+                    // ---- interior iteration of an aggregation item (most iterations of most items): the strip is
+                    // x-interior and every row this iteration touches exists and is y-interior, so nothing is
+                    // clipped or predicated.  Same arithmetic as the general body below, straight-line.
+                    const int y3 = (i - 1) * BH - 2 * R + 2 * wb;      // q rows
+                    const int ye = (i + 2) * BH + 2 * wb;              // stage-1 input rows of band i+2
+                    // step A(i)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        Iraw[t] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)vq, (y3 + t) * (int)fgw4 + 4, 0);
+                    ua[0] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)in1a, ye * (int)fgw4, 0);
+                    ua[1] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)in1a, (ye + 1) * (int)fgw4, 0);
+                    ua[2] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)(in1b + (rsel ? fgw4 : 0u)), ye * (int)fgw4, 0);
+                    ub[0] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)in2a, ye * (int)pitch2, 0);
+                    ub[1] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)in2a, (ye + 1) * (int)pitch2, 0);
+                    ub[2] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)(in2b + (rsel ? pitch2 : 0u)), ye * (int)pitch2, 0);
+                    {
+                        f2 m[2];
+                        int r1[2];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) r1[t] = ph1 * BH + 2 * wb + t;
+                        box2_fast(p1max, p1min, r1, m);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const int ry = r1[t] - R < 0 ? r1[t] - R + RR : r1[t] - R;
+                            float mm = ga[t] * m[t].x;     // compute_ak_and_bk guidedFilter.cu:345-354
+                            float ak = 1.0f * (m[t].y - mm) * gb[t];
+                            float mb2 = 1.0f * ga[t] * ak;
+                            float bk = 1.0f * m[t].x - mb2;
+                            f2 ab = {ak, bk};
+                            ring2[ry * PITCH + HW + lane] = ab;
+                            if (lane >= OW - HW) hout[(2 * wb + t) * HP + lane - (OW - HW)] = ab;
+                        }
+                    }
+                    V3_STAMP(0);
+                    wg_barrier();
+                    V3_STAMP(1);
+                    // step B(i)
+                    const int y2 = (i + 1) * BH - R + 2 * wb;          // a/b rows of band i+1
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        ga[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_ga, (int)vg, (y2 + t) * (int)w4, AUX_G));
+                        gb[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_gb, (int)vg, (y2 + t) * (int)w4, AUX_G));
+                    }
+                    {
+                        f2 m[2];
+                        int r1[2];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const int r = ph2 * BH + 2 * wb + t - R;
+                            r1[t] = r < 0 ? r + RR : r;
+                        }
+                        box2_fast(p2max, p2min, r1, m);
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const float Iv = (float)__builtin_bit_cast(fg_t, Iraw[t]).x;
+                            float tq = m[t].x * Iv;        // compute_q guidedFilter.cu:363-369
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tq + m[t].y), r_q, (int)vq,
+                                                                  (y3 + t) * (int)w4, AUX_NT);
+                        }
+                    }
+                    {
+                        f2* rb = ring1 + ph2 * BH * PITCH;
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) {
+                            const fg_t q1 = __builtin_bit_cast(fg_t, ua[e]);
+                            f2 v;
+                            if (SRC == SRC_IMG) {
+                                v = cost_pair(q1, __builtin_bit_cast(fg_t, ub[e]), cc);
+                            } else {
+                                v.x = __builtin_bit_cast(float, ub[e]);
+                                v.y = (float)q1.x * v.x;
+                            }
+                            if (e == 0) rb[ro_a] = v;
+                            else if (e == 1) rb[ro_a + PITCH] = v;
+                            else if (e2_ok) rb[ro_b] = v;
+                        }
+                    }
+                    V3_STAMP(2);
+                    wg_barrier();
+                    V3_STAMP(3);
+                    continue;
+                }
                 // ------------------------------ step A(i) -----------------------------------------
                 // loads consumed in step B(i): guidance image of the q rows, stage-1 inputs of band i+2
                 const int be = i + 2;
                 const bool ev = be < NB && be * BH < h;
-                if (MODE != GUID && agg) {
-                    rows3(i - 1, ylo, yhi);
+                int y3lo = 0, y3hi = 0;
+                if (MODE != GUID && agg) rows3(i - 1, y3lo, y3hi);
+                const int y3 = y3lo + 2 * wb;                    // q rows of this iteration: y3, y3 + 1
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int y = ylo + 2 * wb + t;
-                        if (y < yhi) Iraw[t] = __builtin_bit_cast(uint32_t, FG1[(unsigned)y * fgw + (unsigned)g2.xc + 1u]);
-                    }
-                }
-                if (ev) {
-#pragma unroll
-                    for (int e = 0; e < NE; ++e) {
-                        // image row of the cell, clamped into the image (wave-uniform for e < 2)
-                        const int y = e < 2 ? min(be * BH + 2 * wb + e, h - 1) : min(be * BH + 2 * wb + rsel, h - 1);
-                        const char* b1 = (const char*)(FG1 + (unsigned)y * fgw);
-                        ua[e] = *(const uint32_t*)(b1 + e_v1[e]);
-                        if (MODE != GUID && agg && SRC == SRC_IMG)
-                            ub[e] = *(const uint32_t*)((const char*)(FG2 + (unsigned)y * fgw) + e_v2[e]);
-                        if (MODE != GUID && agg && SRC == SRC_COST)
-                            ub[e] = *(const uint32_t*)((const char*)(V.cost + ((size_t)slice * h + y) * w) + e_v2[e]);
+                for (int t = 0; t < 2; ++t)    // column + 1 in the padded plane
+                    if (y3 + t < y3hi) Iraw[t] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)vq, (y3 + t) * (int)fgw4 + 4, 0);
+                if (ev) {                      // rows clamped into the image (wave-uniform for cells 0, 1)
+                    const int ye0 = min(be * BH + 2 * wb, h - 1), ye1 = min(be * BH + 2 * wb + 1, h - 1);
+                    const unsigned dy = (unsigned)(ye1 - ye0);   // 1, or 0 on the last image row
+                    ua[0] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)in1a, ye0 * (int)fgw4, 0);
+                    ua[1] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)in1a, ye1 * (int)fgw4, 0);
+                    ua[2] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)(in1b + (rsel ? dy * fgw4 : 0u)), ye0 * (int)fgw4, 0);
+                    if (MODE != GUID && agg) {
+                        ub[0] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)in2a, ye0 * (int)pitch2, 0);
+                        ub[1] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)in2a, ye1 * (int)pitch2, 0);
+                        ub[2] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)(in2b + (rsel ? dy * pitch2 : 0u)), ye0 * (int)pitch2, 0);
                     }
                 }
                 // box means of stage 1, band i (guidance statistics loaded in step B(i-1))
                 rows2(i, ylo, yhi);
-                if (ylo + 2 * wb < yhi && xs < w) {
+                // every window of the band unclipped: x-interior strip, all BH rows exist and are y-interior
+                const bool fast1 = xint1 && i * BH >= HW && (i + 1) * BH <= h;
+                if (fast1 || (ylo + 2 * wb < yhi && xs < w)) {
                     // both rows in one straight-line block (the second one clamped onto the first when
                     // it does not exist, its stores predicated): their LDS reads overlap
                     f2 m[2];
-                    int yy[2];
+                    int yy[2], ry2[2];       // image row, ring-2 row of the a/b values
                     bool ok[2];
+                    if (fast1) {
+                        int r1[2];
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        ok[t] = ylo + 2 * wb + t < yhi;
-                        yy[t] = ok[t] ? ylo + 2 * wb + t : ylo + 2 * wb;
+                        for (int t = 0; t < 2; ++t) {
+                            ok[t] = true;
+                            yy[t] = ylo + 2 * wb + t;
+                            r1[t] = ph1 * BH + 2 * wb + t;           // ring row of y + R = i BH + 2 wb + t
+                            ry2[t] = r1[t] - R < 0 ? r1[t] - R + RR : r1[t] - R;
+                        }
+                        box2_fast(p1max, p1min, r1, m);
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            ok[t] = ylo + 2 * wb + t < yhi;
+                            yy[t] = ok[t] ? ylo + 2 * wb + t : ylo + 2 * wb;
+                            ry2[t] = yy[t] % RR;
+                        }
+                        box2(p1max, p1min, g1.xcw, g1.hx, xint1, yy, m);
                     }
-                    box2(ring1, g1, xint1, yy, m);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const int y = yy[t];
                         if (MODE != AGG && !agg) {
                             float mm = m[t].x * m[t].x;    // pixelMultOnGPU(mean, mean) guidedFilter.cu:112
                             float var = m[t].y - mm;       // pixelSousOnGPU :121
                             float c = (float)(1.0f / ((double)var + A.eps));   // :350
-                            if (g1.xin && ok[t]) {
-                                const unsigned o = (unsigned)y * (unsigned)w + (unsigned)g1.xc;
-                                if (MODE == FUSED) {       // read by other workgroups of this launch
-                                    __hip_atomic_store((gf32*)(V.gmean + o), m[t].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    __hip_atomic_store((gf32*)(V.gcinv + o), c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                } else {
-                                    V.gmean[o] = m[t].x;
-                                    V.gcinv[o] = c;
-                                }
-                                if (V.mean_u8) {           // flToChOnGPU :451-458
-                                    int ci8 = (int)m[t].x;
-                                    V.mean_u8[o] = (ci8 > 255) ? 255 : (uint8_t)ci8;
-                                }
+                            if (ok[t]) {                   // lanes outside the image: dropped by the range check
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, m[t].x), r_ga, (int)vg, yy[t] * (int)w4, AUX_G);
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, c), r_gb, (int)vg, yy[t] * (int)w4, AUX_G);
+                                int ci8 = (int)m[t].x;     // flToChOnGPU :451-458 (no-op without a u8 plane: 0 records)
+                                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)((ci8 > 255) ? 255 : ci8), r_q, (int)vg8, yy[t] * w, 0);
                             }
                         } else {
                             float mm = ga[t] * m[t].x;     // compute_ak_and_bk guidedFilter.cu:345-354
@@ -798,8 +982,8 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                             float bk = 1.0f * m[t].x - mb2;
                             f2 ab = {ak, bk};
                             if (ok[t]) {
-                                ring2[(y % RR) * PITCH + HW + lane] = ab;
-                                if (lane >= OW - HW) hout[(y - ylo) * HP + lane - (OW - HW)] = ab;
+                                ring2[ry2[t] * PITCH + HW + lane] = ab;
+                                if (lane >= OW - HW) hout[(yy[t] - ylo) * HP + lane - (OW - HW)] = ab;
                             }
                         }
                     }
@@ -809,48 +993,54 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 V3_STAMP(1);
                 // ------------------------------ step B(i) -----------------------------------------
                 // loads consumed in step A(i+1): guidance statistics of the a/b rows of band i+1
-                if (MODE != GUID && agg && xs < w) {
+                if (MODE != GUID && agg) {
                     rows2(i + 1, ylo, yhi);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
                         const int y = ylo + 2 * wb + t;
                         if (y < yhi) {
-                            const unsigned o = (unsigned)y * (unsigned)w + (unsigned)g1.xc;
-                            if (MODE == FUSED) {           // written by a guidance item of this launch
-                                ga[t] = __hip_atomic_load((gf32*)(V.mean + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                gb[t] = __hip_atomic_load((gf32*)(V.cinv + o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            } else {
-                                ga[t] = V.mean[o];
-                                gb[t] = V.cinv[o];
-                            }
+                            ga[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_ga, (int)vg, y * (int)w4, AUX_G));
+                            gb[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_gb, (int)vg, y * (int)w4, AUX_G));
                         }
                     }
-                }
-                if (MODE != GUID && agg) {                         // box means of stage 2 -> q of band i-1
-                    rows3(i - 1, ylo, yhi);
-                    if (ylo + 2 * wb < yhi) {
-                        float* __restrict__ qp = V.q + (size_t)slice * h * w;
+                    // box means of stage 2 -> q of band i-1
+                    const bool fast2 = xint2 && (i - 1) * BH - 2 * R >= R + 1 && (i - 1) * BH + BH - R <= h;
+                    if (fast2 || y3 < y3hi) {
                         f2 m[2];
                         int yy[2];
                         bool ok[2];
+                        if (fast2) {
+                            int r1[2];
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            ok[t] = ylo + 2 * wb + t < yhi;
-                            yy[t] = ok[t] ? ylo + 2 * wb + t : ylo + 2 * wb;
+                            for (int t = 0; t < 2; ++t) {
+                                ok[t] = true;
+                                yy[t] = y3 + t;
+                                const int r = ph2 * BH + 2 * wb + t - R;    // ring row of y + R = (i-1) BH - R + 2 wb + t
+                                r1[t] = r < 0 ? r + RR : r;
+                            }
+                            box2_fast(p2max, p2min, r1, m);
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 2; ++t) {
+                                ok[t] = y3 + t < y3hi;
+                                yy[t] = ok[t] ? y3 + t : y3;
+                            }
+                            box2(p2max, p2min, g2.xcw, g2.hx, xint2, yy, m);
                         }
-                        box2(ring2, g2, xint2, yy, m);
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
                             const float Iv = (float)__builtin_bit_cast(fg_t, Iraw[t]).x;
                             float tq = m[t].x * Iv;        // compute_q guidedFilter.cu:363-369
-                            if (g2.xin && ok[t]) __builtin_nontemporal_store(tq + m[t].y, &qp[(unsigned)yy[t] * (unsigned)w + (unsigned)g2.xc]);
+                            if (ok[t])
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tq + m[t].y), r_q, (int)vq,
+                                                                      yy[t] * (int)w4, AUX_NT);
                         }
                     }
                 }
                 if (ev) {                                  // stage-1 inputs of band i+2 -> ring 1
-                    f2* rb = ring1 + ((be * BH) % RR) * PITCH;
+                    f2* rb = ring1 + ph2 * BH * PITCH;
 #pragma unroll
-                    for (int e = 0; e < NE; ++e) {
+                    for (int e = 0; e < 3; ++e) {
                         const fg_t q1 = __builtin_bit_cast(fg_t, ua[e]);
                         f2 v;
                         if (MODE != AGG && !agg) {
@@ -862,7 +1052,9 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                             v.x = __builtin_bit_cast(float, ub[e]);   // copyFromBigToLittleOnGPU :198
                             v.y = (float)q1.x * v.x;                  // pixelMultOnGPU(d_im, d_p) :209
                         }
-                        if (e < 2 || e2_ok) rb[e_ro[e]] = v;
+                        if (e == 0) rb[ro_a] = v;
+                        else if (e == 1) rb[ro_a + PITCH] = v;
+                        else if (e2_ok) rb[ro_b] = v;
                     }
                 }
                 // guidance item of a FUSED launch: every storing wave drains its (sc1) stores of step A, a
@@ -874,6 +1066,9 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             }
         }
         __syncthreads();
+#ifdef SMX_V3_ITEMLOG
+        if (tid == 0 && item < ITEMLOG_MAX) g_itemlog[3 * item + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (tid == 0) s_item = s_next;
     }
 }
@@ -973,6 +1168,13 @@ static int launch_walk3(const v3::Args& a, hipStream_t st) {
 // Aggregation + WTA of slices [s_begin, s_end) of `nviews` (1 or 2) views.  View v uses d_guide[v]
 // as guidance; its cost slices are d_cost[v] (materialised, slice s at (s - s_begin)*w*h) or, when
 // d_cost[v] == NULL, are built on the fly against d_guide[v ^ 1] (nviews == 2) / d_other[0].
+#ifdef SMX_V3_ITEMLOG
+extern "C" __attribute__((visibility("default"))) int smx_debug_read_itemlog(unsigned long long* out, int n) {
+    const int m = 3 * v3::ITEMLOG_MAX;
+    SMX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(v3::g_itemlog), sizeof(unsigned long long) * (n < m ? n : m)));
+    return SMX_OK;
+}
+#endif
 #ifdef SMX_V3_STAMPS
 extern "C" __attribute__((visibility("default"))) int smx_debug_read_stamps(unsigned long long* out, int n) {
     const int m = v3::NWAVE * v3::STAMP_SLOTS;
@@ -996,6 +1198,9 @@ int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     const int R = p->radius;
     const V3Layout L = v3_layout(w, h, R);
     const bool use_cost = d_cost && d_cost[0];
+    // the box waves address every plane through 32-bit buffer offsets, with 0x80000000 as "outside the image"
+    if ((size_t)h * ((size_t)w + 2) * 4 >= 0x80000000ull)
+        return fail(SMX_E_ARG, "aggregate_v3: an image plane of %d x %d exceeds 2 GiB", w, h);
     if (use_cost && nviews == 2 && !d_cost[1])
         return fail(SMX_E_ARG, "aggregate_v3: both views need a cost volume or none");
     char* base = (char*)align_up((size_t)d_ws, 256);
