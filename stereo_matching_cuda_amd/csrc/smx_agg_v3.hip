@@ -233,6 +233,7 @@ __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+template <bool B> struct BoolC { static constexpr bool value = B; };
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f4 ld16_sc1(rsrc_t r, unsigned byteoff) {
@@ -285,7 +286,10 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
     if (tid == 0) s_item = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool nx_valid = false, nx_pd = false, nx_gd = false;     // I/O wave: prefetched state of the next item
     for (;;) {
-        __syncthreads();
+        // LDS-only barriers at the item boundaries too: a full __syncthreads() would make every wave wait for
+        // its last q stores (nothing in the next item depends on them; the hand-off data is drained explicitly
+        // by the I/O wave before it publishes a flag)
+        wg_barrier();
         const int item = s_item;
         if (item >= A.nitems) break;
 #ifdef SMX_V3_ITEMLOG
@@ -825,11 +829,15 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             float ga[2] = {0.0f, 0.0f}, gb[2] = {0.0f, 0.0f};
             uint32_t Iraw[2] = {0, 0};     // raw (value, gradient) halves: converted at use, a step after the load
 
+            // The loop is instantiated per item kind (aggregation / guidance) so that the number of memory
+            // instructions per step is a compile-time fact in each.
+            auto item_loop = [&](auto KIND) __attribute__((always_inline)) {
+            constexpr bool AGGK = decltype(KIND)::value;
             int ph1 = 1;                     // i mod 3: position of band i in the three-band rings (i = -2 first)
             for (int i = -2; i <= NB + 1; ++i, ph1 = ph1 == 2 ? 0 : ph1 + 1) {
                 int ylo, yhi;
                 const int ph2 = ph1 == 0 ? 2 : ph1 - 1;          // (i - 1) mod 3 = (i + 2) mod 3
-                if (MODE != GUID && agg && xint1 && xint2 && (i - 1) * BH >= 3 * R + 1 && (i + 3) * BH <= h) {
+                if (AGGK && xint1 && xint2 && (i - 1) * BH >= 3 * R + 1 && (i + 3) * BH <= h) {
                     // ---- interior iteration of an aggregation item (most iterations of most items): the strip is
                     // x-interior and every row this iteration touches exists and is y-interior, so nothing is
                     // clipped or predicated.  Same arithmetic as the general body below, straight-line.
@@ -917,18 +925,24 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 const int be = i + 2;
                 const bool ev = be < NB && be * BH < h;
                 int y3lo = 0, y3hi = 0;
-                if (MODE != GUID && agg) rows3(i - 1, y3lo, y3hi);
+                if (AGGK) rows3(i - 1, y3lo, y3hi);
                 const int y3 = y3lo + 2 * wb;                    // q rows of this iteration: y3, y3 + 1
+                // Every global access of the loop is issued in every iteration, whether its row exists or not (rows
+                // clamped into the image for loads, the out-of-range lane offset for stores): with a fixed number
+                // of memory instructions per step the waits for the loads of the previous step stay counted ones
+                // instead of degrading to "everything, including the q stores just issued".
+                if (AGGK) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)    // column + 1 in the padded plane
-                    if (y3 + t < y3hi) Iraw[t] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)vq, (y3 + t) * (int)fgw4 + 4, 0);
-                if (ev) {                      // rows clamped into the image (wave-uniform for cells 0, 1)
-                    const int ye0 = min(be * BH + 2 * wb, h - 1), ye1 = min(be * BH + 2 * wb + 1, h - 1);
+                    for (int t = 0; t < 2; ++t)    // column + 1 in the padded plane
+                        Iraw[t] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)vq, min(y3 + t, h - 1) * (int)fgw4 + 4, 0);
+                }
+                {                              // rows clamped into the image (wave-uniform for cells 0, 1)
+                    const int ye0 = min(max(be * BH + 2 * wb, 0), h - 1), ye1 = min(max(be * BH + 2 * wb + 1, 0), h - 1);
                     const unsigned dy = (unsigned)(ye1 - ye0);   // 1, or 0 on the last image row
                     ua[0] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)in1a, ye0 * (int)fgw4, 0);
                     ua[1] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)in1a, ye1 * (int)fgw4, 0);
                     ua[2] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)(in1b + (rsel ? dy * fgw4 : 0u)), ye0 * (int)fgw4, 0);
-                    if (MODE != GUID && agg) {
+                    if (AGGK) {
                         ub[0] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)in2a, ye0 * (int)pitch2, 0);
                         ub[1] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)in2a, ye1 * (int)pitch2, 0);
                         ub[2] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)(in2b + (rsel ? dy * pitch2 : 0u)), ye0 * (int)pitch2, 0);
@@ -965,7 +979,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     }
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        if (MODE != AGG && !agg) {
+                        if (!AGGK) {
                             float mm = m[t].x * m[t].x;    // pixelMultOnGPU(mean, mean) guidedFilter.cu:112
                             float var = m[t].y - mm;       // pixelSousOnGPU :121
                             float c = (float)(1.0f / ((double)var + A.eps));   // :350
@@ -993,22 +1007,20 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 V3_STAMP(1);
                 // ------------------------------ step B(i) -----------------------------------------
                 // loads consumed in step A(i+1): guidance statistics of the a/b rows of band i+1
-                if (MODE != GUID && agg) {
+                if (AGGK) {
                     rows2(i + 1, ylo, yhi);
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        const int y = ylo + 2 * wb + t;
-                        if (y < yhi) {
-                            ga[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_ga, (int)vg, y * (int)w4, AUX_G));
-                            gb[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_gb, (int)vg, y * (int)w4, AUX_G));
-                        }
+                        const int y = min(ylo + 2 * wb + t, h - 1);    // clamped: unused if the row does not exist
+                        ga[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_ga, (int)vg, y * (int)w4, AUX_G));
+                        gb[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_gb, (int)vg, y * (int)w4, AUX_G));
                     }
                     // box means of stage 2 -> q of band i-1
                     const bool fast2 = xint2 && (i - 1) * BH - 2 * R >= R + 1 && (i - 1) * BH + BH - R <= h;
+                    f2 m[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
+                    int yy[2] = {y3, y3};
+                    bool ok[2] = {false, false};
                     if (fast2 || y3 < y3hi) {
-                        f2 m[2];
-                        int yy[2];
-                        bool ok[2];
                         if (fast2) {
                             int r1[2];
 #pragma unroll
@@ -1027,14 +1039,13 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                             }
                             box2(p2max, p2min, g2.xcw, g2.hx, xint2, yy, m);
                         }
+                    }
 #pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            const float Iv = (float)__builtin_bit_cast(fg_t, Iraw[t]).x;
-                            float tq = m[t].x * Iv;        // compute_q guidedFilter.cu:363-369
-                            if (ok[t])
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tq + m[t].y), r_q, (int)vq,
-                                                                      yy[t] * (int)w4, AUX_NT);
-                        }
+                    for (int t = 0; t < 2; ++t) {      // always issued: a row that does not exist is dropped by the range check
+                        const float Iv = (float)__builtin_bit_cast(fg_t, Iraw[t]).x;
+                        float tq = m[t].x * Iv;            // compute_q guidedFilter.cu:363-369
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tq + m[t].y), r_q, (int)(ok[t] ? vq : OOB),
+                                                              min(yy[t], h - 1) * (int)w4, AUX_NT);
                     }
                 }
                 if (ev) {                                  // stage-1 inputs of band i+2 -> ring 1
@@ -1043,7 +1054,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     for (int e = 0; e < 3; ++e) {
                         const fg_t q1 = __builtin_bit_cast(fg_t, ua[e]);
                         f2 v;
-                        if (MODE != AGG && !agg) {
+                        if (!AGGK) {
                             v.x = (float)q1.x;            // chToFlOnGPU guidedFilter.cu:442-449
                             v.y = v.x * v.x;              // pixelMultOnGPU(d_im, d_im) :111
                         } else if (SRC == SRC_IMG) {
@@ -1059,13 +1070,16 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 }
                 // guidance item of a FUSED launch: every storing wave drains its (sc1) stores of step A, a
                 // step old by now, before the barrier behind which the I/O wave publishes the band
-                if (MODE == FUSED && !agg) drain_vmem();
+                if (MODE == FUSED && !AGGK) drain_vmem();
                 V3_STAMP(2);
                 wg_barrier();
                 V3_STAMP(3);
             }
+            };
+            if (MODE == AGG || (MODE == FUSED && agg)) item_loop(BoolC<true>{});
+            else item_loop(BoolC<false>{});
         }
-        __syncthreads();
+        wg_barrier();
 #ifdef SMX_V3_ITEMLOG
         if (tid == 0 && item < ITEMLOG_MAX) g_itemlog[3 * item + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
