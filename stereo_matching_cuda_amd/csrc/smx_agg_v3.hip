@@ -768,12 +768,19 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     }
                 }
             };
-            // The same for a band whose windows are all unclipped (the strip is x-interior and every row of the
-            // band is y-interior and exists): no selects, one area, and the ring rows follow from the band's
-            // position in the ring (r1 = ring row of y + R) without any division.
+            // The same for a band whose rows all exist and are y-interior: the ring rows follow from the band's
+            // position in the ring (r1 = ring row of y + R) without any division, the window height is 2R+1.
+            // In an x-interior strip (xint) there is no select and one area; in the first / last strip of the
+            // image the x-clipping of the general box stays (per-lane width xcw, hx = has a left tap).
             const float area_full = (float)(HW * HW), ra_full = rcp_s[HW * HW];
-            auto box2_fast = [&](const f2* pmax, const f2* pmin, const int (&r1)[2], f2 (&m)[2]) {
+            auto box2_fast = [&](const f2* pmax, const f2* pmin, const int (&r1)[2], bool xint, int xcw, bool hx, f2 (&m)[2]) {
                 f2 s11[2], s10[2], s01[2], s00[2], val[2];
+                float area = area_full, ra = ra_full;
+                if (!xint) {
+                    area = (float)(xcw * HW);
+                    ra = rcp_s[xcw * HW];
+                }
+                const bool left = xint || hx;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     int r0 = r1[t] - HW;
@@ -784,20 +791,23 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 bool slow = false;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    f2 v = s11[t] - s10[t];
+                    f2 v = s11[t];
+                    f2 u = v - s10[t];
+                    v = left ? u : v;
                     v = v - s01[t];
-                    v = v + s00[t];
+                    u = v + s00[t];
+                    v = left ? u : v;
                     val[t] = v;
-                    m[t].x = div_small_int(v.x, area_full, ra_full);
-                    m[t].y = div_small_int(v.y, area_full, ra_full);
+                    m[t].x = div_small_int(v.x, area, ra);
+                    m[t].y = div_small_int(v.y, area, ra);
                     slow = slow || div_needs_exact(v.x) || div_needs_exact(v.y);
                 }
                 if (__any(slow)) {
                     asm volatile("; exact-division slow path");
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        m[t].x = 1.0f * val[t].x / area_full;
-                        m[t].y = 1.0f * val[t].y / area_full;
+                        m[t].x = 1.0f * val[t].x / area;
+                        m[t].y = 1.0f * val[t].y / area;
                     }
                 }
             };
@@ -837,28 +847,34 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             for (int i = -2; i <= NB + 1; ++i, ph1 = ph1 == 2 ? 0 : ph1 + 1) {
                 int ylo, yhi;
                 const int ph2 = ph1 == 0 ? 2 : ph1 - 1;          // (i - 1) mod 3 = (i + 2) mod 3
-                if (AGGK && xint1 && xint2 && (i - 1) * BH >= 3 * R + 1 && (i + 3) * BH <= h) {
-                    // ---- interior iteration of an aggregation item (most iterations of most items): the strip is
-                    // x-interior and every row this iteration touches exists and is y-interior, so nothing is
-                    // clipped or predicated.  Same arithmetic as the general body below, straight-line.
+                if (AGGK && xs < w && (i - 1) * BH >= 3 * R + 1 && (i + 1) * BH <= h) {
+                    auto interior = [&](auto XINT) __attribute__((always_inline)) {
+                    constexpr bool XI = decltype(XINT)::value;
+                    // ---- y-interior iteration of an aggregation item (most iterations of most items): every window
+                    // row of both box stages exists and is y-interior, so no row is predicated and the window
+                    // height is fixed; in an x-interior strip (XI) no window is clipped in x either.  The rows
+                    // loaded for later bands are clamped into the image.  Same arithmetic as the general body
+                    // below, straight-line.
                     const int y3 = (i - 1) * BH - 2 * R + 2 * wb;      // q rows
-                    const int ye = (i + 2) * BH + 2 * wb;              // stage-1 input rows of band i+2
+                    const int ye = min((i + 2) * BH + 2 * wb, h - 1);  // stage-1 input rows of band i+2 (clamped)
+                    const int ye1 = min((i + 2) * BH + 2 * wb + 1, h - 1);
+                    const unsigned dy = (unsigned)(ye1 - ye);          // 1, or 0 on the last image row
                     // step A(i)
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
                         Iraw[t] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)vq, (y3 + t) * (int)fgw4 + 4, 0);
                     ua[0] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)in1a, ye * (int)fgw4, 0);
-                    ua[1] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)in1a, (ye + 1) * (int)fgw4, 0);
-                    ua[2] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)(in1b + (rsel ? fgw4 : 0u)), ye * (int)fgw4, 0);
+                    ua[1] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)in1a, ye1 * (int)fgw4, 0);
+                    ua[2] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)(in1b + (rsel ? dy * fgw4 : 0u)), ye * (int)fgw4, 0);
                     ub[0] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)in2a, ye * (int)pitch2, 0);
-                    ub[1] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)in2a, (ye + 1) * (int)pitch2, 0);
-                    ub[2] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)(in2b + (rsel ? pitch2 : 0u)), ye * (int)pitch2, 0);
+                    ub[1] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)in2a, ye1 * (int)pitch2, 0);
+                    ub[2] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)(in2b + (rsel ? dy * pitch2 : 0u)), ye * (int)pitch2, 0);
                     {
                         f2 m[2];
                         int r1[2];
 #pragma unroll
                         for (int t = 0; t < 2; ++t) r1[t] = ph1 * BH + 2 * wb + t;
-                        box2_fast(p1max, p1min, r1, m);
+                        box2_fast(p1max, p1min, r1, XI, g1.xcw, g1.hx, m);
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
                             const int ry = r1[t] - R < 0 ? r1[t] - R + RR : r1[t] - R;
@@ -875,11 +891,11 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     wg_barrier();
                     V3_STAMP(1);
                     // step B(i)
-                    const int y2 = (i + 1) * BH - R + 2 * wb;          // a/b rows of band i+1
+                    const int y2 = (i + 1) * BH - R + 2 * wb;          // a/b rows of band i+1 (clamped: unused if missing)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        ga[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_ga, (int)vg, (y2 + t) * (int)w4, AUX_G));
-                        gb[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_gb, (int)vg, (y2 + t) * (int)w4, AUX_G));
+                        ga[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_ga, (int)vg, min(y2 + t, h - 1) * (int)w4, AUX_G));
+                        gb[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_gb, (int)vg, min(y2 + t, h - 1) * (int)w4, AUX_G));
                     }
                     {
                         f2 m[2];
@@ -889,7 +905,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                             const int r = ph2 * BH + 2 * wb + t - R;
                             r1[t] = r < 0 ? r + RR : r;
                         }
-                        box2_fast(p2max, p2min, r1, m);
+                        box2_fast(p2max, p2min, r1, XI, g2.xcw, g2.hx, m);
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
                             const float Iv = (float)__builtin_bit_cast(fg_t, Iraw[t]).x;
@@ -898,7 +914,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                                                                   (y3 + t) * (int)w4, AUX_NT);
                         }
                     }
-                    {
+                    if ((i + 2) * BH < h) {                              // band i+2 has rows
                         f2* rb = ring1 + ph2 * BH * PITCH;
 #pragma unroll
                         for (int e = 0; e < 3; ++e) {
@@ -918,6 +934,9 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     V3_STAMP(2);
                     wg_barrier();
                     V3_STAMP(3);
+                    };
+                    if (xint1 && xint2) interior(BoolC<true>{});
+                    else interior(BoolC<false>{});
                     continue;
                 }
                 // ------------------------------ step A(i) -----------------------------------------
@@ -950,8 +969,8 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 }
                 // box means of stage 1, band i (guidance statistics loaded in step B(i-1))
                 rows2(i, ylo, yhi);
-                // every window of the band unclipped: x-interior strip, all BH rows exist and are y-interior
-                const bool fast1 = xint1 && i * BH >= HW && (i + 1) * BH <= h;
+                // all BH rows of the band exist and are y-interior
+                const bool fast1 = xs < w && i * BH >= HW && (i + 1) * BH <= h;
                 if (fast1 || (ylo + 2 * wb < yhi && xs < w)) {
                     // both rows in one straight-line block (the second one clamped onto the first when
                     // it does not exist, its stores predicated): their LDS reads overlap
@@ -967,7 +986,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                             r1[t] = ph1 * BH + 2 * wb + t;           // ring row of y + R = i BH + 2 wb + t
                             ry2[t] = r1[t] - R < 0 ? r1[t] - R + RR : r1[t] - R;
                         }
-                        box2_fast(p1max, p1min, r1, m);
+                        box2_fast(p1max, p1min, r1, xint1, g1.xcw, g1.hx, m);
                     } else {
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
@@ -1016,7 +1035,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                         gb[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_gb, (int)vg, y * (int)w4, AUX_G));
                     }
                     // box means of stage 2 -> q of band i-1
-                    const bool fast2 = xint2 && (i - 1) * BH - 2 * R >= R + 1 && (i - 1) * BH + BH - R <= h;
+                    const bool fast2 = (i - 1) * BH - 2 * R >= R + 1 && (i - 1) * BH + BH - R <= h;
                     f2 m[2] = {{0.0f, 0.0f}, {0.0f, 0.0f}};
                     int yy[2] = {y3, y3};
                     bool ok[2] = {false, false};
@@ -1030,7 +1049,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                                 const int r = ph2 * BH + 2 * wb + t - R;    // ring row of y + R = (i-1) BH - R + 2 wb + t
                                 r1[t] = r < 0 ? r + RR : r;
                             }
-                            box2_fast(p2max, p2min, r1, m);
+                            box2_fast(p2max, p2min, r1, xint2, g2.xcw, g2.hx, m);
                         } else {
 #pragma unroll
                             for (int t = 0; t < 2; ++t) {
