@@ -280,11 +280,9 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
     // issue arbitration against the box waves that share their SIMDs
     if (wave < W_B0) __builtin_amdgcn_s_setprio(3);
 
-    // The ticket of the NEXT item is taken by the I/O wave near the end of the current one, and the flags
-    // that item will look at first (left neighbour finished? guidance of its strip complete?) are read
-    // right behind it: no workgroup-wide stall on an atomic or a flag at item boundaries.
+    // The ticket of the NEXT item is taken by the I/O wave two band iterations before the end of the current
+    // one: no workgroup-wide stall on an atomic at item boundaries.
     if (tid == 0) s_item = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bool nx_valid = false, nx_pd = false, nx_gd = false;     // I/O wave: prefetched state of the next item
     for (;;) {
         // LDS-only barriers at the item boundaries too: a full __syncthreads() would make every wave wait for
         // its last q stores (nothing in the next item depends on them; the hand-off data is drained explicitly
@@ -395,11 +393,9 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             // =====================================================================================
             unsigned* const myflag = flags_i + (size_t)sv * K + k;
             unsigned* const gready = MODE == FUSED ? A.gready + (size_t)view * K + k : nullptr;
-            bool gdone = nx_valid && nx_gd;      // guidance of this strip complete (FUSED aggregation items)
-            bool pred_done = !pred || (nx_valid && nx_pd);
-            nx_valid = false;
-            unsigned nx_tk = 0, nx_pf = 0, nx_gf = 0;   // next ticket / its neighbour's flag / its guidance flag
-            bool nx_haspred = false, nx_hasg = false;
+            bool gdone = false;                  // guidance of this strip complete (FUSED aggregation items)
+            bool pred_done = !pred;              // left neighbour finished
+            unsigned nx_tk = 0;                  // ticket of the next item
             const size_t recs = (size_t)NB * REC_F2;      // float2 per (parity, slice-view)
             const rsrc_t r_in = mk_rsrc(hand_i + ((size_t)((k - 1) & 1) * nsv_i + sv) * recs, recs * 8);
             const rsrc_t r_out = mk_rsrc(hand_i + ((size_t)(k & 1) * nsv_i + sv) * recs, recs * 8);
@@ -442,27 +438,14 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 // drained at the end of step B(i-1), a step later -> publish it
                 if (MODE == FUSED && !agg && lane == 0 && i - 1 >= 0 && i - 1 < NB)
                     flag_store(gready, i - 1 == NB - 1 ? FLAG_DONE : (unsigned)i);
-                if (i == NB - 1) {                         // 1. ticket of the next item (returns one step later)
-                    if (lane == 0)
-                        nx_tk = __hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                } else if (i == NB) {                      // 2. publish it; read the flags it will need first
-                    const unsigned t = __builtin_amdgcn_readfirstlane(nx_tk);
-                    if (lane == 0) s_next = (int)t;
-                    if (t < (unsigned)A.nitems) {
-                        const bool nagg = MODE == AGG || (MODE == FUSED && (int)t >= A.nguid);
-                        const int nn = nagg ? nsv : (MODE == FUSED ? A.nviews : nsv);
-                        const int ti = (MODE == FUSED && nagg) ? (int)t - A.nguid : (int)t;
-                        const int nk = ti / nn, nsvi = ti - nk * nn;
-                        unsigned* const nfl = (nagg ? A.flags : (MODE == FUSED ? A.gflags : A.flags)) + (size_t)nsvi * K + nk;
-                        nx_haspred = nk > 0;
-                        if (nx_haspred) nx_pf = flag_load(nfl - 1);
-                        nx_hasg = MODE == FUSED && nagg;
-                        if (nx_hasg) nx_gf = flag_load(A.gready + (size_t)(nsvi / A.nslices) * K + nk);
-                    }
-                } else if (i == NB + 1) {                  // 3. both loads are back (drain above)
-                    nx_valid = true;
-                    nx_pd = !nx_haspred || __builtin_amdgcn_readfirstlane(nx_pf) == FLAG_DONE;
-                    nx_gd = nx_hasg && __builtin_amdgcn_readfirstlane(nx_gf) == FLAG_DONE;
+                // Next item: its ticket is taken at the END of step A(NB-2), as the last memory instruction of the
+                // step, and step B starts with a wait that leaves exactly that one in flight: the latency of the
+                // atomic (~1 us under load) passes under two busy steps instead of being waited for by the whole
+                // workgroup in a nearly empty drain iteration.  (Built with the atomic optimizer off: it would
+                // broadcast -- i.e. wait for -- the result right behind the atomic.)
+                if (i == NB - 1) {                         // the ticket is back (drain above): publish it
+                    asm volatile("" : "+v"(nx_tk));        // keep the compiler from consuming it (and waiting) earlier
+                    if (lane == 0) s_next = (int)nx_tk;
                 }
                 if (MODE != GUID && agg && pred) {
                     // halo columns + stage-2 carries loaded at B(i-1) -> ring 2 / staging
@@ -505,11 +488,15 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     wait_pred(2 * i + 6);
                     if (lane < BH / 2) c1reg = ld16_sc1(r_in, (unsigned)((i + 2) * REC_F2 * 8 + lane * 16));
                 }
+                const bool take = i == NB - 2;             // ticket of the next item: last memory instruction of the step
+                if (take && lane == 0)
+                    nx_tk = __hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 V3_STAMP(0);
                 wg_barrier();
                 V3_STAMP(1);
                 // ------------------------------ step B(i), t = 2i + 5 ---------------------------
-                drain_vmem();
+                if (take) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");   // everything but the ticket
+                else drain_vmem();
                 if (succ && lane == 0 && i >= -1) flag_store(myflag, (unsigned)(2 * i + 3));
 
                 if (pred && lane < BH / 2) *(f4*)&cin[0][2 * lane] = c1reg;
