@@ -426,6 +426,33 @@ def test_pair_step_is_capturable_in_a_hip_graph(tsukuba_gray, tsukuba_oracle):
         _eq(r[k], tsukuba_oracle[k], k)
 
 
+def test_two_pipelines_on_two_devices(tsukuba_gray, tsukuba_oracle):
+    """Each PairPipeline launches on its OWN device's current stream whatever device is current in the
+    calling thread (device.py::_on_device); two shards on two GPUs merged by hand must give the oracle's
+    result.  Needs two GPUs: skipped on the one-GPU test box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    from stereo_matching_cuda_amd.device import PairPipeline
+    Il, Ir = tsukuba_gray
+    pipes = []
+    for g, dev in enumerate(("cuda:0", "cuda:1")):
+        pipe = PairPipeline(384, 288, 16, dminl=-15, dminr=0, s_begin=8 * g, s_end=8 * (g + 1), device=dev)
+        dl, dr = torch.from_numpy(Il).to(dev), torch.from_numpy(Ir).to(dev)
+        pipe.aggregate(dl, dr)                 # current device stays cuda:0 for both
+        pipes.append(pipe)
+    for pipe in pipes:
+        torch.cuda.synchronize(pipe.device)
+        pipe.check_status()
+    merged = torch.minimum(pipes[0].keys, pipes[1].keys.to("cuda:0"))
+    pipes[0].keys.copy_(merged)
+    pipes[0].finish()
+    torch.cuda.synchronize()
+    r = pipes[0].results()
+    for k in ("dmapl", "dmapr", "bestl", "bestr", "occlusion", "filled"):
+        _eq(r[k], tsukuba_oracle[k], k)
+
+
 @pytest.mark.parametrize("path", [2, 1])
 def test_device_pipeline_chunked_equals_unchunked(tsukuba_gray, tsukuba_oracle, path):
     Il, Ir = tsukuba_gray
