@@ -427,7 +427,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     }
                 }
             };
-            for (int i = -2; i <= NB + 1; ++i) {
+            for (int i = -2; i <= NB; ++i) {
                 int lo, hi;
                 // ------------------------------ step A(i), t = 2i + 4 ---------------------------
                 // everything this wave issued to global memory was issued at the start of the
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             // =====================================================================================
             const bool ccol = lane + 64 < TW;             // this lane also scans ring column lane + 64
             f2 S1 = ident, S2 = ident, S1b = ident, S2b = ident;
-            for (int i = -2; i <= NB + 1; ++i) {
+            for (int i = -2; i <= NB; ++i) {
                 int lo, hi;
                 if (MODE != GUID && agg) {
                     rows2(i - 1, lo, hi);                  // A(i): stage 2, band i-1
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 // running row sum left of the next strip's first column
                 if (OW - 1 >= jlo && OW - 1 < jhi) ((float*)&cout[st][srow])[comp] = row[2 * (OW - 1)];
             };
-            for (int i = -2; i <= NB + 1; ++i) {
+            for (int i = -2; i <= NB; ++i) {
                 int lo, hi;
                 rows1(i + 1, lo, hi);                      // A(i): stage 1, band i+1
                 rowscan(ring1, 0, lo, hi, jlo1, jhi1);
@@ -831,7 +831,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             auto item_loop = [&](auto KIND) __attribute__((always_inline)) {
             constexpr bool AGGK = decltype(KIND)::value;
             int ph1 = 1;                     // i mod 3: position of band i in the three-band rings (i = -2 first)
-            for (int i = -2; i <= NB + 1; ++i, ph1 = ph1 == 2 ? 0 : ph1 + 1) {
+            for (int i = -2; i <= NB; ++i, ph1 = ph1 == 2 ? 0 : ph1 + 1) {
                 int ylo, yhi;
                 const int ph2 = ph1 == 0 ? 2 : ph1 - 1;          // (i - 1) mod 3 = (i + 2) mod 3
                 if (AGGK && xs < w && (i - 1) * BH >= 3 * R + 1 && (i + 1) * BH <= h) {
