@@ -259,6 +259,8 @@ static_assert(BH <= 32, "the row scan maps rows to the lanes of half a wave");
 template <int MODE, int SRC>
 __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
     __shared__ __attribute__((aligned(16))) f2 ring1[RR * PITCH];
+    // ring 1 keeps stage-1 row y at ring row y mod RR; ring 2 keeps a/b row y at (y + R) mod RR, so that the
+    // R-lagged bands of stage 2 start at a band slot like those of stage 1 and never wrap inside a band
     __shared__ __attribute__((aligned(16))) f2 ring2[MODE != GUID ? RR * PITCH : 2];
     // hand-off staging (all global hand-off traffic goes through the I/O wave, one step delayed):
     __shared__ __attribute__((aligned(16))) f2 cin[2][BH];    // row carries in : stage -> rows of the band
@@ -320,8 +322,8 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
 
         // column scan of rows [lo, hi) for the ring column `col` of this lane (LANE = COLUMN); runs of
         // consecutive ring rows, so the LDS addresses of a batch are one base + immediates
-        auto colscan = [&](f2* ring, int col, int lo, int hi, f2& S) {
-            int rr = lo % RR, n = hi - lo;
+        auto colscan = [&](f2* ring, int shift, int col, int lo, int hi, f2& S) {
+            int rr = (lo + shift) % RR, n = hi - lo;
             while (n > 0) {
                 const int run = min(n, RR - rr);
                 f2* p = ring + rr * PITCH + col;
@@ -349,8 +351,8 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
         // the ring (the common case) is straight-line code in batches of 8 rows: the reads of the next batch
         // are issued before the adds and writes of the current one, so the LDS latency is exposed once per
         // column group instead of once per batch (and once per row in the remainder)
-        auto colscan_band = [&](f2* ring, int lo, int hi, f2& S, f2& Sb, bool ccol) {
-            const int rr = lo % RR;
+        auto colscan_band = [&](f2* ring, int shift, int lo, int hi, f2& S, f2& Sb, bool ccol) {
+            const int rr = (lo + shift) % RR;
             if (hi - lo == BH && rr + BH <= RR) {
                 constexpr int CB = 8, NCB = (BH + CB - 1) / CB;
                 auto group = [&](f2* p, f2& acc) {
@@ -377,8 +379,8 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 if (ccol) group(p + 64, Sb);
                 return;
             }
-            colscan(ring, lane, lo, hi, S);
-            if (ccol) colscan(ring, lane + 64, lo, hi, Sb);
+            colscan(ring, shift, lane, lo, hi, S);
+            if (ccol) colscan(ring, shift, lane + 64, lo, hi, Sb);
         };
 
         if (wave == W_IO) {
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     for (int e = 0; e < NHU; ++e) {
                         const int r = hu_r[e], c = hu_c[e];
                         if (r < hhi - hlo && c < HW) {
-                            int rr = hlo % RR + r;
+                            int rr = (hlo + R) % RR + r;
                             rr = rr >= RR ? rr - RR : rr;
                             f2* dst = ring2 + rr * PITCH + c;
                             dst[0] = lo2(hreg[e]);
@@ -551,14 +553,14 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 if (MODE != GUID && agg) {
                     rows2(i - 1, lo, hi);                  // A(i): stage 2, band i-1
                     if (i - 1 == 0) { S2 = ident; S2b = ident; }
-                    colscan_band(ring2, lo, hi, S2, S2b, ccol);
+                    colscan_band(ring2, R, lo, hi, S2, S2b, ccol);
                 }
                 V3_STAMP(0);
                 wg_barrier();
                 V3_STAMP(1);
                 rows1(i + 1, lo, hi);                      // B(i): stage 1, band i+1
                 if (i + 1 == 0) { S1 = ident; S1b = ident; }
-                colscan_band(ring1, lo, hi, S1, S1b, ccol);
+                colscan_band(ring1, 0, lo, hi, S1, S1b, ccol);
                 V3_STAMP(2);
                 wg_barrier();
                 V3_STAMP(3);
@@ -574,11 +576,11 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             const int jlo1 = max(0, -cs1), jhi1 = min(TW, w - cs1);   // ring-1 columns inside the image
             const int jlo2 = max(0, -cs2), jhi2 = min(TW, w - cs2);
             const int srow = lane & 31, comp = lane >> 5;
-            auto rowscan = [&](f2* ring, int st, int ylo, int yhi, int jlo, int jhi) {
+            auto rowscan = [&](f2* ring, int shift, int st, int ylo, int yhi, int jlo, int jhi) {
                 if (srow >= yhi - ylo || jhi <= jlo) return;
                 const int y = ylo + srow;
                 float acc = pred ? ((const float*)&cin[st][srow])[comp] : -0.0f;
-                float* row = (float*)(ring + (y % RR) * PITCH) + comp;   // column c of this component: row[2 c]
+                float* row = (float*)(ring + ((y + shift) % RR) * PITCH) + comp;   // column c of this component: row[2 c]
                 if (jlo == 0 && jhi == TWMAX) {
                     // the common case (a strip inside the image at radius 9): 83 columns, fully unrolled so
                     // that every LDS wait is a counted one
@@ -645,13 +647,13 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             for (int i = -2; i <= NB; ++i) {
                 int lo, hi;
                 rows1(i + 1, lo, hi);                      // A(i): stage 1, band i+1
-                rowscan(ring1, 0, lo, hi, jlo1, jhi1);
+                rowscan(ring1, 0, 0, lo, hi, jlo1, jhi1);
                 V3_STAMP(0);
                 wg_barrier();
                 V3_STAMP(1);
                 if (MODE != GUID && agg) {                         // B(i): stage 2, band i
                     rows2(i, lo, hi);
-                    rowscan(ring2, 1, lo, hi, jlo2, jhi2);
+                    rowscan(ring2, R, 1, lo, hi, jlo2, jhi2);
                 }
                 V3_STAMP(2);
                 wg_barrier();
@@ -714,7 +716,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             // in that order, then a true division by the clipped window area).  Branch-free: all ten
             // LDS reads are issued before the first use; clipped taps are read from a valid dummy
             // address and dropped by a select; the exact-division fix-up is one rare branch at the end.
-            auto box2 = [&](const f2* pmax, const f2* pmin, int xcw, bool hx, bool xint, const int (&yy)[2], f2 (&m)[2]) {
+            auto box2 = [&](const f2* pmax, const f2* pmin, int shift, int xcw, bool hx, bool xint, const int (&yy)[2], f2 (&m)[2]) {
                 f2 s11[2], s10[2], s01[2], s00[2], val[2];
                 float area[2], ra[2];
                 bool hy[2];
@@ -724,7 +726,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     const int ymin = yy[t] - R - 1;
                     hy[t] = ymin >= 0;
                     const int ych = ymax - (hy[t] ? ymin : -1);
-                    const int o1 = (ymax % RR) * PITCH, o0 = ((hy[t] ? ymin : 0) % RR) * PITCH;
+                    const int o1 = ((ymax + shift) % RR) * PITCH, o0 = (((hy[t] ? ymin : 0) + shift) % RR) * PITCH;
                     s11[t] = pmax[o1]; s10[t] = pmin[o1];
                     s01[t] = pmax[o0]; s00[t] = pmin[o0];
                     const int ai = (xint ? HW : xcw) * ych;
@@ -864,7 +866,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                         box2_fast(p1max, p1min, r1, XI, g1.xcw, g1.hx, m);
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            const int ry = r1[t] - R < 0 ? r1[t] - R + RR : r1[t] - R;
+                            const int ry = r1[t];          // ring 2 keeps a/b row y at ring row (y + R) mod RR
                             float mm = ga[t] * m[t].x;     // compute_ak_and_bk guidedFilter.cu:345-354
                             float ak = 1.0f * (m[t].y - mm) * gb[t];
                             float mb2 = 1.0f * ga[t] * ak;
@@ -889,8 +891,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                         int r1[2];
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            const int r = ph2 * BH + 2 * wb + t - R;
-                            r1[t] = r < 0 ? r + RR : r;
+                            r1[t] = ph2 * BH + 2 * wb + t;       // ring-2 row of y + R: (y + 2R) mod RR
                         }
                         box2_fast(p2max, p2min, r1, XI, g2.xcw, g2.hx, m);
 #pragma unroll
@@ -971,7 +972,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                             ok[t] = true;
                             yy[t] = ylo + 2 * wb + t;
                             r1[t] = ph1 * BH + 2 * wb + t;           // ring row of y + R = i BH + 2 wb + t
-                            ry2[t] = r1[t] - R < 0 ? r1[t] - R + RR : r1[t] - R;
+                            ry2[t] = r1[t];
                         }
                         box2_fast(p1max, p1min, r1, xint1, g1.xcw, g1.hx, m);
                     } else {
@@ -979,9 +980,9 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                         for (int t = 0; t < 2; ++t) {
                             ok[t] = ylo + 2 * wb + t < yhi;
                             yy[t] = ok[t] ? ylo + 2 * wb + t : ylo + 2 * wb;
-                            ry2[t] = yy[t] % RR;
+                            ry2[t] = (yy[t] + R) % RR;
                         }
-                        box2(p1max, p1min, g1.xcw, g1.hx, xint1, yy, m);
+                        box2(p1max, p1min, 0, g1.xcw, g1.hx, xint1, yy, m);
                     }
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -1033,8 +1034,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                             for (int t = 0; t < 2; ++t) {
                                 ok[t] = true;
                                 yy[t] = y3 + t;
-                                const int r = ph2 * BH + 2 * wb + t - R;    // ring row of y + R = (i-1) BH - R + 2 wb + t
-                                r1[t] = r < 0 ? r + RR : r;
+                                r1[t] = ph2 * BH + 2 * wb + t;    // ring-2 row of y + R: (y + 2R) mod RR = (i-1) BH + 2 wb + t
                             }
                             box2_fast(p2max, p2min, r1, xint2, g2.xcw, g2.hx, m);
                         } else {
@@ -1043,7 +1043,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                                 ok[t] = y3 + t < y3hi;
                                 yy[t] = ok[t] ? y3 + t : y3;
                             }
-                            box2(p2max, p2min, g2.xcw, g2.hx, xint2, yy, m);
+                            box2(p2max, p2min, R, g2.xcw, g2.hx, xint2, yy, m);
                         }
                     }
 #pragma unroll
