@@ -254,7 +254,7 @@ constexpr int REC_F2 = 2 * BH + BH * HP;          // float2 per band record
 constexpr int NHU = (BH * HP / 2 + 63) / 64;      // 16-byte halo units per lane of the I/O wave
 static_assert(BH % 2 == 0 && HP % 2 == 0 && (REC_F2 % 2) == 0, "16-byte hand-off units");
 static_assert(BH == 2 * NWB, "every box wave owns two rows of a band");
-static_assert(BH <= 32, "the row scan maps rows to the lanes of half a wave");
+static_assert(BH % 2 == 0 && BH / 2 <= 16, "the row scan maps half of the rows to 16 lanes of each half wave");
 
 template <int MODE, int SRC>
 __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
@@ -567,17 +567,24 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             }
         } else if (wave == W_R) {
             // =====================================================================================
-            // row-scan wave: lanes 0..25 carry the first component (p or a) of rows 0..25 of the band,
-            // lanes 32..57 the second one (I*p or b) of the same rows -- the cost of an LDS write grows with
+            // row-scan wave: every active lane carries ONE component (p or a / I*p or b) of one row of the band
+            // -- the cost of an LDS write grows with
             // the dwords per lane (ds_write_b64 14, ds_write_b128 27 cycles of issue), not with the active
             // lanes, so one dword per lane and column halves the dominant term of the dependent chain.
             // Reads run one batch of 8 columns ahead of the adds.
             // =====================================================================================
             const int jlo1 = max(0, -cs1), jhi1 = min(TW, w - cs1);   // ring-1 columns inside the image
             const int jlo2 = max(0, -cs2), jhi2 = min(TW, w - cs2);
-            const int srow = lane & 31, comp = lane >> 5;
+            // lane -> (row of the band, component): each 32-lane group (the unit of LDS banking for dword accesses)
+            // takes half of the rows with both components, lanes 0-12 / 16-28 = first / second component.  The
+            // 13 first-component lanes of a group then hit 13 distinct even banks and the 13 second-component
+            // lanes 13 distinct odd ones (row stride 2 PITCH = 170 dwords = 10 mod 32): conflict-free, where 26
+            // rows of one component in a group would be two-way conflicts on the 16 even banks.
+            constexpr int HB = BH / 2;
+            const int srow = (lane & 15) + HB * (lane >> 5), comp = (lane >> 4) & 1;
+            const bool sact = (lane & 15) < HB;
             auto rowscan = [&](f2* ring, int shift, int st, int ylo, int yhi, int jlo, int jhi) {
-                if (srow >= yhi - ylo || jhi <= jlo) return;
+                if (!sact || srow >= yhi - ylo || jhi <= jlo) return;
                 const int y = ylo + srow;
                 float acc = pred ? ((const float*)&cin[st][srow])[comp] : -0.0f;
                 float* row = (float*)(ring + ((y + shift) % RR) * PITCH) + comp;   // column c of this component: row[2 c]
