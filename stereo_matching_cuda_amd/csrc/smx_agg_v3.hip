@@ -412,12 +412,14 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                 hu_r[e] = t / (HP / 2);
                 hu_c[e] = (t - hu_r[e] * (HP / 2)) * 2;
             }
+            unsigned pseen = 0, gseen = 0;       // last values read from the neighbour's / the guidance flag (both only grow)
             auto wait_pred = [&](int t) {
-                if (pred_done) return;
                 const unsigned need = (unsigned)t;
+                if (pred_done || pseen >= need) return;      // a neighbour that runs far ahead costs one read per many bands
                 const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
                 for (;;) {
                     const unsigned f = flag_load(myflag - 1);
+                    pseen = __builtin_amdgcn_readfirstlane(f);
                     if (f >= need) { pred_done = f == FLAG_DONE; break; }
                     __builtin_amdgcn_s_sleep(4);
                     // bounded spin: give up after 2 s (100 MHz counter) or as soon as any workgroup
@@ -474,8 +476,9 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     // the guidance item of this strip must have stored (and drained) them
                     const unsigned need = (unsigned)(i + 2);
                     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-                    for (;;) {
+                    while (gseen < need) {
                         const unsigned f = flag_load(gready);
+                        gseen = __builtin_amdgcn_readfirstlane(f);
                         if (f >= need) { gdone = f == FLAG_DONE; break; }
                         __builtin_amdgcn_s_sleep(4);
                         if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull || flag_load(A.status) != 0u) {
