@@ -203,6 +203,14 @@ int smx_dev_filter(const smx_params* p, const uint8_t* d_image, int w, int h, ui
 int smx_dev_detect_occlusion(const smx_params* p, float* d_dL, const float* d_dR, int dOcclusion,
                              int w, int h, void* stream);
 int smx_dev_fill_occlusion(float* d_disp, int w, int h, float vMin, void* stream);
+/* main.cu:112-155 behind the aggregation, for both views at once: d_keys / d_best / d_dmap hold the left
+ * view in [0, n) and the right one in [n, 2n), n = w*h.  best <- preset, dmap <- 0, the winning slice of
+ * every key applied (smx_dev_init_wta + smx_dev_apply_keys), d_occlusion <- left map after the LR check
+ * (smx_dev_detect_occlusion with dOcclusion), d_filled <- d_occlusion filled (smx_dev_fill_occlusion with
+ * vMin).  Three launches instead of seven; same results (tested against the per-call sequence). */
+int smx_dev_finish_pair(const smx_params* p, const int64_t* d_keys, int w, int h, int dminl, int dminr,
+                        int dOcclusion, float vMin, float* d_best, float* d_dmap, float* d_occlusion,
+                        float* d_filled, void* stream);
 
 /* Host-side helpers for the packed key (same encoding as the kernels). */
 int64_t smx_pack_key(float cost, uint32_t slice);

@@ -78,6 +78,7 @@ SIGNATURES = {
     "smx_dev_init_wta": (_i, [_vp, _vp, _i64, _vp]),
     "smx_dev_detect_occlusion": (_i, [_PP, _vp, _vp, _i, _i, _i, _vp]),
     "smx_dev_fill_occlusion": (_i, [_vp, _i, _i, _f, _vp]),
+    "smx_dev_finish_pair": (_i, [_PP, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "smx_pack_key": (_i64, [_f, _u32]),
     "smx_unpack_key": (None, [_i64, C.POINTER(_f), C.POINTER(_u32)]),
     "smx_set_agg_path": (_i, [_i]),

@@ -201,7 +201,21 @@ int smx_dev_detect_occlusion(const smx_params* p, float* d_dL, const float* d_dR
 
 int smx_dev_fill_occlusion(float* d_disp, int w, int h, float vMin, void* stream) {
     SMX_ARG(d_disp && w >= 1 && h >= 1);
-    return launch_fill_occlusion(d_disp, w, h, vMin, (hipStream_t)stream);
+    return launch_fill_occlusion(d_disp, d_disp, w, h, vMin, (hipStream_t)stream);
+}
+
+// main.cu:112-155 behind the aggregation, both views, in three launches (presets + winning slices + copy of
+// the left map; LR check; filling out of place) instead of the seven of the per-call sequence
+int smx_dev_finish_pair(const smx_params* p, const int64_t* d_keys, int w, int h, int dminl, int dminr,
+                        int dOcclusion, float vMin, float* d_best, float* d_dmap, float* d_occlusion,
+                        float* d_filled, void* stream) {
+    SMX_ARG(p && d_keys && d_best && d_dmap && d_occlusion && d_filled && w >= 1 && h >= 1);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = (int64_t)w * h;
+    int rc;
+    if ((rc = launch_finish_keys(d_keys, n, dminl, dminr, d_best, d_dmap, d_occlusion, st))) return rc;
+    if ((rc = launch_detect_occlusion(p, d_occlusion, d_dmap + n, dOcclusion, w, h, st))) return rc;
+    return launch_fill_occlusion(d_occlusion, d_filled, w, h, vMin, st);
 }
 
 int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uint8_t* d_other,
@@ -519,7 +533,6 @@ int smx_stereo_pair(const smx_params* p, const uint8_t* gray_l, const uint8_t* g
                                       dminr, 0, size_d, nullptr))) return rc;
     }
     if ((rc = smx_dev_init_keys(keysL, 2 * nn, nullptr))) return rc;
-    if ((rc = smx_dev_init_wta(bestL, mapL, 2 * nn, nullptr))) return rc;
     // main.cu:133-134, both views per kernel launch
     if (v3_supported(p) && g_agg_path != 1) {
         const uint8_t* guide[2] = {dL.as<uint8_t>(), dR.as<uint8_t>()};
@@ -547,13 +560,9 @@ int smx_stereo_pair(const smx_params* p, const uint8_t* gray_l, const uint8_t* g
                                         ws_bytes, nullptr)))
             return rc;
     }
-    if ((rc = smx_dev_apply_keys(keysL, nn, dminl, bestL, mapL, nullptr))) return rc;
-    if ((rc = smx_dev_apply_keys(keysR, nn, dminr, bestR, mapR, nullptr))) return rc;
-    // main.cu:140-155
-    SMX_HIP(hipMemcpyAsync(occ.p, mapL, fb, hipMemcpyDeviceToDevice, nullptr));
-    if ((rc = smx_dev_detect_occlusion(p, occ.as<float>(), mapR, dminl - 100, w, h, nullptr))) return rc;
-    SMX_HIP(hipMemcpyAsync(fil.p, occ.p, fb, hipMemcpyDeviceToDevice, nullptr));
-    if ((rc = smx_dev_fill_occlusion(fil.as<float>(), w, h, (float)dminl, nullptr))) return rc;
+    // main.cu:112-118 presets, winning slices, main.cu:140-155
+    if ((rc = smx_dev_finish_pair(p, keysL, w, h, dminl, dminr, dminl - 100, (float)dminl, bestL, mapL,
+                                  occ.as<float>(), fil.as<float>(), nullptr))) return rc;
     SMX_HIP(hipDeviceSynchronize());
     if ((rc = smx_dev_agg_status(ws.p))) return rc;
     struct { void* dst; const void* src; size_t b; } copies[] = {

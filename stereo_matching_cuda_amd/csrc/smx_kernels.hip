@@ -319,6 +319,30 @@ __global__ void k_apply_keys(const int64_t* __restrict__ keys, int64_t n, int dm
     }
 }
 
+// main.cu:112-141 for both views in one pass: the reference's presets (k_init_wta), the winning slice of
+// each key (k_apply_keys) and the copy of the left disparity map that the LR check then overwrites.
+// keys / best / dmap hold the left view in [0, n) and the right view in [n, 2n).
+__global__ void k_finish_keys(const int64_t* __restrict__ keys, int64_t n, int dminl, int dminr,
+                              float* __restrict__ best, float* __restrict__ dmap, float* __restrict__ occlusion) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 2 * n) return;
+    float b = __builtin_bit_cast(float, 0x7F7F7F7Fu);   // main.cu:112
+    float d = 0.0f;                                      // main.cu:117
+    const int64_t key = keys[k];
+    if (key != KEY_IDENTITY) {
+        float q;
+        uint32_t s;
+        unpack_key(key, &q, &s);
+        if (1.0f * b >= 1.0f * q) {                      // dispSelectOnGPU guidedFilter.cu:403-411
+            d = (float)((k < n ? dminl : dminr) + (int)s);
+            b = q;
+        }
+    }
+    best[k] = b;
+    dmap[k] = d;
+    if (k < n) occlusion[k] = d;                         // main.cu:141
+}
+
 // =====================================================================================
 // occlusion   (occlusion.cu:3-15 detect_occlusionOnGPU, :134-176 fill_occlusionOnGPU1)
 // =====================================================================================
@@ -336,10 +360,13 @@ __global__ void k_detect_occlusion(float* dL, const float* __restrict__ dR, int 
 // One wave per row, two ballot sweeps: nearest valid value at-or-left, then at-or-right.
 // Pure selection (no arithmetic), so it equals the reference's per-pixel searches, including
 // its benign in-place race.  Dynamic LDS: w floats.
-__global__ __launch_bounds__(64) void k_fill_occlusion(float* disp, int w, int h, float vMin) {
+// With in != disp the filled map is written to disp and `in` stays untouched (main.cu:153 copy folded in):
+// the sweeps only ever read values that are valid in the input, and those are never overwritten.
+__global__ __launch_bounds__(64) void k_fill_occlusion(const float* in, float* disp, int w, int h, float vMin) {
     extern __shared__ float sLeft[];
     const int lane = threadIdx.x;
-    float* row = disp + (int64_t)blockIdx.x * w;
+    const float* row = in + (int64_t)blockIdx.x * w;
+    float* out = disp + (int64_t)blockIdx.x * w;
     float carry = vMin;
     for (int c0 = 0; c0 < w; c0 += 64) {
         int x = c0 + lane;
@@ -368,7 +395,9 @@ __global__ __launch_bounds__(64) void k_fill_occlusion(float* disp, int w, int h
             int dX = (int)v;
             if (!((float)dX >= vMin)) {
                 float l = sLeft[x];
-                row[x] = l > right ? l : right;
+                out[x] = l > right ? l : right;
+            } else if (in != disp) {
+                out[x] = v;
             }
         }
         int first = mask ? __ffsll((long long)mask) - 1 : 0;
@@ -531,10 +560,18 @@ int launch_filter(const smx_params* p, const uint8_t* I, uint8_t* mean, float* v
     return SMX_OK;
 }
 
-int launch_fill_occlusion(float* disp, int w, int h, float vMin, hipStream_t st) {
+int launch_fill_occlusion(const float* src, float* disp, int w, int h, float vMin, hipStream_t st) {
     size_t lds = (size_t)w * sizeof(float);
     if (lds > 64 * 1024) return fail(SMX_E_ARG, "fill_occlusion: width %d exceeds LDS row buffer", w);
-    hipLaunchKernelGGL(k_fill_occlusion, dim3(h), dim3(64), lds, st, disp, w, h, vMin);
+    hipLaunchKernelGGL(k_fill_occlusion, dim3(h), dim3(64), lds, st, src, disp, w, h, vMin);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+int launch_finish_keys(const int64_t* keys, int64_t n, int dminl, int dminr, float* best, float* dmap,
+                       float* occlusion, hipStream_t st) {
+    hipLaunchKernelGGL(k_finish_keys, dim3(cdiv(2 * n, 256)), dim3(256), 0, st, keys, n, dminl, dminr, best, dmap,
+                       occlusion);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

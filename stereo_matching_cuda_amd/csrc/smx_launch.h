@@ -20,7 +20,9 @@ int launch_init_wta(float* best, float* dmap, int64_t n, hipStream_t st);
 int launch_apply_keys(const int64_t* keys, int64_t n, int dmin, float* best, float* dmap, hipStream_t st);
 int launch_detect_occlusion(const smx_params* p, float* dL, const float* dR, int dOcc, int w, int h,
                             hipStream_t st);
-int launch_fill_occlusion(float* disp, int w, int h, float vMin, hipStream_t st);
+int launch_fill_occlusion(const float* src, float* disp, int w, int h, float vMin, hipStream_t st);
+int launch_finish_keys(const int64_t* keys, int64_t n, int dminl, int dminr, float* best, float* dmap,
+                       float* occlusion, hipStream_t st);
 int launch_filter(const smx_params* p, const uint8_t* I, uint8_t* mean, float* var, int w, int h,
                   hipStream_t st);
 }  // namespace smx

@@ -92,7 +92,16 @@ class PairPipeline:
                 _dp(self.keys[view]), _dp(self.mean[view]), _dp(agg), _dp(self.ws), self.ws_bytes, st))
 
     def finish(self):
-        """Keys -> best/dmap (reference presets, dispSelect rule), LR check, filling."""
+        """Keys -> best/dmap (reference presets, dispSelect rule), LR check, filling: main.cu:112-155 in one
+        call (smx_dev_finish_pair: three launches)."""
+        with self._on_device():
+            L, P, st = self.lib, C.byref(self.params), self._stream()
+            _lib.check(L.smx_dev_finish_pair(P, _dp(self.keys), self.w, self.h, self.dminl, self.dminr,
+                                             self.dminl - 100, float(self.dminl), _dp(self.best), _dp(self.dmap),
+                                             _dp(self.occlusion), _dp(self.filled), st))
+
+    def finish_per_call(self):
+        """The same through the per-stage entry points (the reference's call sequence, seven launches)."""
         with self._on_device():
             L, P, st = self.lib, C.byref(self.params), self._stream()
             _lib.check(L.smx_dev_init_wta(_dp(self.best), _dp(self.dmap), 2 * self.n, st))

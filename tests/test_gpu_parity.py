@@ -426,6 +426,26 @@ def test_pair_step_is_capturable_in_a_hip_graph(tsukuba_gray, tsukuba_oracle):
         _eq(r[k], tsukuba_oracle[k], k)
 
 
+def test_finish_pair_equals_the_per_call_sequence(tsukuba_gray, tsukuba_oracle):
+    """smx_dev_finish_pair (three launches) against smx_dev_init_wta + 2 x smx_dev_apply_keys + copy +
+    smx_dev_detect_occlusion + copy + smx_dev_fill_occlusion, and both against the oracle."""
+    import torch
+    from stereo_matching_cuda_amd.device import PairPipeline
+    Il, Ir = tsukuba_gray
+    dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
+    pipe = PairPipeline(384, 288, 16, dminl=-15, dminr=0)
+    pipe.aggregate(dl, dr)
+    pipe.finish()
+    fused = pipe.results()
+    for t in (pipe.best, pipe.dmap, pipe.occlusion, pipe.filled):
+        t.fill_(-7.0)
+    pipe.finish_per_call()
+    percall = pipe.results()
+    for k in ("dmapl", "dmapr", "bestl", "bestr", "occlusion", "filled"):
+        _eq(fused[k], percall[k], k)
+        _eq(fused[k], tsukuba_oracle[k], k)
+
+
 def test_two_pipelines_on_two_devices(tsukuba_gray, tsukuba_oracle):
     """Each PairPipeline launches on its OWN device's current stream whatever device is current in the
     calling thread (device.py::_on_device); two shards on two GPUs merged by hand must give the oracle's
