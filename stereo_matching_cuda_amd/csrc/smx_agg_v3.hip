@@ -1276,15 +1276,17 @@ int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     };
     // first 256 B: status word of the call (smx_dev_agg_status)
     unsigned* status = (unsigned*)carve(256);
+    // right behind it the control block of the guidance items (ticket + hand-off flags + ready counters):
+    // one memset clears both
+    char* gctrl = (char*)carve(v3_flag_bytes(L, 2 * nviews));
     if (oom) return fail(SMX_E_WS, "aggregate_v3: workspace too small");
-    SMX_HIP(hipMemsetAsync(status, 0, 256, st));
+    SMX_HIP(hipMemsetAsync(status, 0, 256 + v3_flag_bytes(L, 2 * nviews), st));
     // fixed part: image planes, guidance statistics, guidance scratch + control
     v3::fg_t* FG[2];
     float *meanI[2], *cinv[2];
     for (int i = 0; i < 2; ++i) FG[i] = (v3::fg_t*)carve(L.fg * 4);
     for (int v = 0; v < nviews; ++v) { meanI[v] = (float*)carve(L.plane * 4); cinv[v] = (float*)carve(L.plane * 4); }
     v3::f2* ghand = (v3::f2*)carve((size_t)nviews * L.sv_hand * 4);
-    char* gctrl = (char*)carve(v3_flag_bytes(L, 2 * nviews));   // ticket + hand-off flags + ready counters
     const int total = s_end - s_begin;
     // per slice-view: q plane (unless the caller's volume is written directly) + scratch + flags
     const bool own_q = !(d_agg && d_agg[0]);
@@ -1335,8 +1337,6 @@ int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     }
     unsigned* const gflags = (unsigned*)(gctrl + V3_CTRL_BYTES);
     unsigned* const gready = gflags + (size_t)nviews * L.K;
-    SMX_HIP(hipMemsetAsync(gctrl, 0, v3_flag_bytes(L, 2 * nviews), st));
-    ++nl;
     if (total <= 0) {
         g.nslices = 1; g.nsv = nviews; g.nitems = nviews * L.K; g.nviews = nviews;
         g.hand = ghand;
