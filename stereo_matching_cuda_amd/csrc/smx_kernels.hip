@@ -359,18 +359,24 @@ __global__ void k_detect_occlusion(float* dL, const float* __restrict__ dR, int 
 
 // One wave per row, two ballot sweeps: nearest valid value at-or-left, then at-or-right.
 // Pure selection (no arithmetic), so it equals the reference's per-pixel searches, including
-// its benign in-place race.  Dynamic LDS: w floats.
+// its benign in-place race.  Dynamic LDS: 2 w floats.
 // With in != disp the filled map is written to disp and `in` stays untouched (main.cu:153 copy folded in):
 // the sweeps only ever read values that are valid in the input, and those are never overwritten.
 __global__ __launch_bounds__(64) void k_fill_occlusion(const float* in, float* disp, int w, int h, float vMin) {
-    extern __shared__ float sLeft[];
+    extern __shared__ float sbuf[];          // [0, w): nearest valid value at-or-left, [w, 2w): the row itself
+    float* sLeft = sbuf;
+    float* sVal = sbuf + w;
     const int lane = threadIdx.x;
     const float* row = in + (int64_t)blockIdx.x * w;
     float* out = disp + (int64_t)blockIdx.x * w;
+    // the row goes to LDS first, all loads in flight at once: the sweeps below are chains of ballots and
+    // must not wait for memory chunk by chunk
+    for (int x = lane; x < w; x += 64) sVal[x] = row[x];
+    __syncthreads();
     float carry = vMin;
     for (int c0 = 0; c0 < w; c0 += 64) {
         int x = c0 + lane;
-        float v = x < w ? row[x] : 0.0f;
+        float v = x < w ? sVal[x] : 0.0f;
         bool valid = x < w && v >= vMin;
         unsigned long long mask = __ballot(valid);
         unsigned long long lower = mask & ((2ull << lane) - 1ull);
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(64) void k_fill_occlusion(const float* in, float* d
     carry = vMin;
     for (int c0 = ((w - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
         int x = c0 + lane;
-        float v = x < w ? row[x] : 0.0f;
+        float v = x < w ? sVal[x] : 0.0f;
         bool valid = x < w && v >= vMin;
         unsigned long long mask = __ballot(valid);
         unsigned long long upper = mask & (~0ull << lane);
@@ -561,8 +567,10 @@ int launch_filter(const smx_params* p, const uint8_t* I, uint8_t* mean, float* v
 }
 
 int launch_fill_occlusion(const float* src, float* disp, int w, int h, float vMin, hipStream_t st) {
-    size_t lds = (size_t)w * sizeof(float);
-    if (lds > 64 * 1024) return fail(SMX_E_ARG, "fill_occlusion: width %d exceeds LDS row buffer", w);
+    size_t lds = (size_t)w * 2 * sizeof(float);
+    if (lds > 128 * 1024) return fail(SMX_E_ARG, "fill_occlusion: width %d exceeds LDS row buffer", w);
+    if (lds > 64 * 1024)
+        SMX_HIP(hipFuncSetAttribute((const void*)k_fill_occlusion, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_fill_occlusion, dim3(h), dim3(64), lds, st, src, disp, w, h, vMin);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
