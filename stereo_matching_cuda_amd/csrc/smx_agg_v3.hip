@@ -772,7 +772,9 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
             // In an x-interior strip (xint) there is no select and one area; in the first / last strip of the
             // image the x-clipping of the general box stays (per-lane width xcw, hx = has a left tap).
             const float area_full = (float)(HW * HW), ra_full = rcp_s[HW * HW];
-            auto box2_fast = [&](const f2* pmax, const f2* pmin, const int (&r1)[2], bool xint, int xcw, bool hx, f2 (&m)[2]) {
+            // `mid` runs between the issue of the eight LDS reads and their first use: the interior iteration puts
+            // its global loads there, so that their issue time hides LDS latency instead of preceding it.
+            auto box2_fast = [&](const f2* pmax, const f2* pmin, const int (&r1)[2], bool xint, int xcw, bool hx, f2 (&m)[2], auto mid) {
                 f2 s11[2], s10[2], s01[2], s00[2], val[2];
                 float area = area_full, ra = ra_full;
                 if (!xint) {
@@ -787,6 +789,9 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     s11[t] = pmax[r1[t] * PITCH]; s10[t] = pmin[r1[t] * PITCH];
                     s01[t] = pmax[r0 * PITCH];    s00[t] = pmin[r0 * PITCH];
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                mid();
+                __builtin_amdgcn_sched_barrier(0);
                 bool slow = false;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -858,22 +863,24 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     const int ye = min((i + 2) * BH + 2 * wb, h - 1);  // stage-1 input rows of band i+2 (clamped)
                     const int ye1 = min((i + 2) * BH + 2 * wb + 1, h - 1);
                     const unsigned dy = (unsigned)(ye1 - ye);          // 1, or 0 on the last image row
-                    // step A(i)
+                    // step A(i): the loads consumed in step B go out behind the LDS reads of the box
+                    auto loadsA = [&]() {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
-                        Iraw[t] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)vq, (y3 + t) * (int)fgw4 + 4, 0);
-                    ua[0] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)in1a, ye * (int)fgw4, 0);
-                    ua[1] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)in1a, ye1 * (int)fgw4, 0);
-                    ua[2] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)(in1b + (rsel ? dy * fgw4 : 0u)), ye * (int)fgw4, 0);
-                    ub[0] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)in2a, ye * (int)pitch2, 0);
-                    ub[1] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)in2a, ye1 * (int)pitch2, 0);
-                    ub[2] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)(in2b + (rsel ? dy * pitch2 : 0u)), ye * (int)pitch2, 0);
+                        for (int t = 0; t < 2; ++t)
+                            Iraw[t] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)vq, (y3 + t) * (int)fgw4 + 4, 0);
+                        ua[0] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)in1a, ye * (int)fgw4, 0);
+                        ua[1] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)in1a, ye1 * (int)fgw4, 0);
+                        ua[2] = __builtin_amdgcn_raw_buffer_load_b32(r_fg1, (int)(in1b + (rsel ? dy * fgw4 : 0u)), ye * (int)fgw4, 0);
+                        ub[0] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)in2a, ye * (int)pitch2, 0);
+                        ub[1] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)in2a, ye1 * (int)pitch2, 0);
+                        ub[2] = __builtin_amdgcn_raw_buffer_load_b32(r_in2, (int)(in2b + (rsel ? dy * pitch2 : 0u)), ye * (int)pitch2, 0);
+                    };
                     {
                         f2 m[2];
                         int r1[2];
 #pragma unroll
                         for (int t = 0; t < 2; ++t) r1[t] = ph1 * BH + 2 * wb + t;
-                        box2_fast(p1max, p1min, r1, XI, g1.xcw, g1.hx, m);
+                        box2_fast(p1max, p1min, r1, XI, g1.xcw, g1.hx, m, loadsA);
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
                             const int ry = r1[t];          // ring 2 keeps a/b row y at ring row (y + R) mod RR
@@ -891,11 +898,32 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                     V3_STAMP(1);
                     // step B(i)
                     const int y2 = (i + 1) * BH - R + 2 * wb;          // a/b rows of band i+1 (clamped: unused if missing)
+                    // behind the LDS reads of the stage-2 box: the guidance loads for the next step, and the cost of
+                    // band i+2 (inputs loaded in step A) -> ring 1
+                    auto loadsB = [&]() {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        ga[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_ga, (int)vg, min(y2 + t, h - 1) * (int)w4, AUX_G));
-                        gb[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_gb, (int)vg, min(y2 + t, h - 1) * (int)w4, AUX_G));
-                    }
+                        for (int t = 0; t < 2; ++t) {
+                            ga[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_ga, (int)vg, min(y2 + t, h - 1) * (int)w4, AUX_G));
+                            gb[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_gb, (int)vg, min(y2 + t, h - 1) * (int)w4, AUX_G));
+                        }
+                        if ((i + 2) * BH < h) {                          // band i+2 has rows
+                            f2* rb = ring1 + ph2 * BH * PITCH;
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) {
+                                const fg_t q1 = __builtin_bit_cast(fg_t, ua[e]);
+                                f2 v;
+                                if (SRC == SRC_IMG) {
+                                    v = cost_pair(q1, __builtin_bit_cast(fg_t, ub[e]), cc);
+                                } else {
+                                    v.x = __builtin_bit_cast(float, ub[e]);
+                                    v.y = (float)q1.x * v.x;
+                                }
+                                if (e == 0) rb[ro_a] = v;
+                                else if (e == 1) rb[ro_a + PITCH] = v;
+                                else if (e2_ok) rb[ro_b] = v;
+                            }
+                        }
+                    };
                     {
                         f2 m[2];
                         int r1[2];
@@ -903,30 +931,13 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                         for (int t = 0; t < 2; ++t) {
                             r1[t] = ph2 * BH + 2 * wb + t;       // ring-2 row of y + R: (y + 2R) mod RR
                         }
-                        box2_fast(p2max, p2min, r1, XI, g2.xcw, g2.hx, m);
+                        box2_fast(p2max, p2min, r1, XI, g2.xcw, g2.hx, m, loadsB);
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
                             const float Iv = (float)__builtin_bit_cast(fg_t, Iraw[t]).x;
                             float tq = m[t].x * Iv;        // compute_q guidedFilter.cu:363-369
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tq + m[t].y), r_q, (int)vq,
                                                                   (y3 + t) * (int)w4, AUX_NT);
-                        }
-                    }
-                    if ((i + 2) * BH < h) {                              // band i+2 has rows
-                        f2* rb = ring1 + ph2 * BH * PITCH;
-#pragma unroll
-                        for (int e = 0; e < 3; ++e) {
-                            const fg_t q1 = __builtin_bit_cast(fg_t, ua[e]);
-                            f2 v;
-                            if (SRC == SRC_IMG) {
-                                v = cost_pair(q1, __builtin_bit_cast(fg_t, ub[e]), cc);
-                            } else {
-                                v.x = __builtin_bit_cast(float, ub[e]);
-                                v.y = (float)q1.x * v.x;
-                            }
-                            if (e == 0) rb[ro_a] = v;
-                            else if (e == 1) rb[ro_a + PITCH] = v;
-                            else if (e2_ok) rb[ro_b] = v;
                         }
                     }
                     V3_STAMP(2);
@@ -984,7 +995,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                             r1[t] = ph1 * BH + 2 * wb + t;           // ring row of y + R = i BH + 2 wb + t
                             ry2[t] = r1[t];
                         }
-                        box2_fast(p1max, p1min, r1, xint1, g1.xcw, g1.hx, m);
+                        box2_fast(p1max, p1min, r1, xint1, g1.xcw, g1.hx, m, [] {});
                     } else {
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
@@ -1046,7 +1057,7 @@ __global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
                                 yy[t] = y3 + t;
                                 r1[t] = ph2 * BH + 2 * wb + t;    // ring-2 row of y + R: (y + 2R) mod RR = (i-1) BH + 2 wb + t
                             }
-                            box2_fast(p2max, p2min, r1, xint2, g2.xcw, g2.hx, m);
+                            box2_fast(p2max, p2min, r1, xint2, g2.xcw, g2.hx, m, [] {});
                         } else {
 #pragma unroll
                             for (int t = 0; t < 2; ++t) {
