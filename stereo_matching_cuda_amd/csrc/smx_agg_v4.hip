@@ -1,0 +1,1037 @@
+// smx_agg_v4.hip -- fused guided-filter aggregation for gfx950, throughput form: cost build ->
+// integral (p, I*p) -> box -> a_k, b_k -> integral (a, b) -> box -> q in ONE kernel, with a_k, b_k never
+// leaving the CU.  Reference: guidedFilter.cu:171-238, costVolume.cu:163-190, integral.cu:78-131.
+//
+// Work item = (slice-view sv, strip k): a column strip of OW = 64 output columns, walked top -> bottom in
+// bands of BH = 32 rows by one 512-thread workgroup.  TWO workgroups share a CU (72 KB of LDS each): while
+// one of them sits in a latency-bound phase (the sequential scans) the other one fills the SIMDs, which is
+// what the one-workgroup-per-CU predecessor (smx_agg_v3.hip) could not do.  Two LDS rings of 52 rows x 83
+// columns of float2 hold the integral images of stage 1 (p, I*p) and stage 2 (a, b): a band of box means
+// needs BH + 2R + 1 rows.
+//
+// Exactness: every prefix sum keeps the reference's order (sequential left -> right in a row, then
+// sequential top -> bottom in a column; integral.cu:82-86, 124-128), the box mean its tap order
+// (guidedFilter.cu:305-318).  The row scans of a strip start from the running row sums of the strip to its
+// left, the column scans keep their running sums in registers down the strip.  Stage 1 recomputes the 2R+1
+// columns it shares with its left neighbour; stage 2 lags stage 1 by R rows and R columns and receives the
+// 2R+1 finished integral columns it shares with its left neighbour from that neighbour (hand-off record).
+//
+// Iteration i of an item (four workgroup barriers):
+//   W(i)  all waves: cost of band i (loaded in X(i-1)) -> ring 1; a_k, b_k of band i-1 (computed in X(i-1))
+//         -> ring 2; the left neighbour's record i -> LDS (row carries, stage-2 halo columns)
+//   R(i)  wave 0: row scan of stage 1, band i | wave 1: row scan of stage 2, band i-1   (LANE = ROW x component)
+//   C(i)  waves 0, 1: column scan of stage 1, band i | wave 2: column scan of stage 2, band i-1 (LANE = COLUMN)
+//   X(i)  all waves, LANE = COLUMN, 4 rows each: record i -> global; box means of stage 2 -> q rows of band
+//         i-1 (lagged by 2R) -> HBM; box means of stage 1 -> a_k, b_k of band i (lagged by R, registers);
+//         loads for iteration i+1
+// Every global access is a row-major 256-byte run issued as a buffer instruction.
+//
+// Items are handed out by a ticket counter in strip-major order, so the left neighbour of an item always
+// holds an earlier ticket (it is running or done: no deadlock whatever the dispatch order).  The hand-off is
+// the sc1 form of the guide (write-through 16-byte stores, every storing wave drained before the workgroup
+// barrier behind which ONE lane publishes a band counter; sc1 loads behind a relaxed poll of that counter
+// and a workgroup barrier; no acquire fence).
+//
+// Must be compiled with -ffp-contract=off.
+#include <string.h>
+
+#include <type_traits>
+
+#include "smx_common.h"
+#include "smx_launch.h"
+
+namespace smx {
+namespace v4 {
+
+constexpr int OW = 64;                  // output columns per strip = one wave
+constexpr int RMAX = 9;                 // largest supported box radius
+constexpr int HWMAX = 2 * RMAX + 1;     // halo / overlap columns
+constexpr int TWMAX = OW + HWMAX;       // ring columns in use (83 at R = 9)
+constexpr int PITCH = 85;               // float2 per ring row: odd, so the LANE = ROW dword accesses of the row
+                                        // scan (row stride 2 PITCH dwords = 10 mod 32) hit distinct banks
+constexpr int NT = 512;
+constexpr int NWAVE = NT / 64;
+constexpr int BH = 32;                  // band height
+constexpr int RPW = BH / NWAVE;         // rows of a band per wave in the LANE = COLUMN phases
+constexpr int RR = 52;                  // ring rows
+static_assert(RR >= BH + 2 * RMAX + 2, "a band of box means needs BH + 2R + 1 rows");
+static_assert(RR % RPW == 0 && BH % RPW == 0, "a wave's group of RPW consecutive ring rows never wraps");
+static_assert(RPW == 4, "the box / cost code below is written for four rows per wave");
+
+enum Src { SRC_IMG = 0, SRC_COST = 1 };
+
+typedef _Float16 fg_t __attribute__((ext_vector_type(2)));   // (pixel value, x-derivative), exact in fp16
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+
+struct View {
+    const fg_t* FG1;      // this view's image plane [h][w+2], sentinel columns at x = -1 and x = w
+    const fg_t* FG2;      // the other view's (SRC_IMG)
+    const float* cost;    // SRC_COST: [slice][h][w]
+    const float* mean;    // mean_I [h][w]
+    const float* cinv;    // 1/(var_I + eps) [h][w]
+    float* q;             // out: [slice][h][w]
+    int d0;               // disparity of local slice 0
+};
+
+struct Args {
+    View v[2];
+    int w, h, R, K, NI, nslices, nsv, nitems;
+    f2* hand;             // hand-off records [parity][sv][iteration] (see REC_F2)
+    unsigned* flags;      // [sv][K]  published-record counters (zeroed before every launch)
+    unsigned* ticket;     // work-item counter              (zeroed before every launch)
+    unsigned* status;     // != 0: a flag wait timed out (results invalid)
+    CostConst cc;
+};
+
+// RN(1/d) for d = 0 .. 361 (box areas are (xmax-xmin)*(ymax-ymin) <= 19*19)
+struct RcpTable {
+    float v[HWMAX * HWMAX + 1];
+    constexpr RcpTable() : v() {
+        v[0] = 0.0f;
+        for (int i = 1; i <= HWMAX * HWMAX; ++i) v[i] = 1.0f / (float)i;
+    }
+};
+static __constant__ RcpTable kRcp = RcpTable();
+
+// x / d, correctly rounded, for an integer-valued d in [1, 361] with r = RN(1/d): one residual correction
+// step (Markstein).  Bit-identical to IEEE division for |x| >= 2^-100 (exhaustive over the significand for
+// every area: tools/check_fastdiv.c); callers route smaller |x| (incl. +-0, whose sign the correction would
+// lose) and non-finite x to the true division.
+__device__ __forceinline__ float div_small_int(float x, float d, float r) {
+    float q = x * r;
+    float e = __builtin_fmaf(-q, d, x);
+    return __builtin_fmaf(e, r, q);
+}
+__device__ __forceinline__ bool div_needs_exact(float x) {
+    const float ax = fabsf(x);
+    return !(ax >= 0x1p-100f && ax < __builtin_inff());   // tiny, zero, inf or NaN
+}
+
+// p = (1-alpha)*min(|I1 - I2|, 7) + alpha*min(|g1 - g2|, 2) and I1*p  (costVolume.cu:187,
+// guidedFilter.cu:209).  The halves convert exactly, so the f32 operations equal the reference's; the
+// sentinel 60000 of an out-of-range partner saturates both terms = the border constant (:184).
+__device__ __forceinline__ f2 cost_pair(fg_t q1, fg_t q2, const CostConst& cc) {
+    const float a1 = (float)q1.x, b1 = (float)q1.y, a2 = (float)q2.x, b2 = (float)q2.y;
+    float t1 = fabsf(a1 - a2);
+    float t2 = fabsf(b1 - b2);
+    float m1 = t1 < cc.th_color ? t1 : cc.th_color;
+    float m2 = t2 < cc.th_grad ? t2 : cc.th_grad;
+    float x = cc.oma * m1;
+    float z = cc.alpha * m2;
+    f2 r;
+    r.x = x + z;
+    r.y = a1 * r.x;
+    return r;
+}
+
+// ---- hand-off accesses: sc1 (bypass this CU's L1, write through the XCD's L2) ----------------
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int AUX_SC1 = 16;
+constexpr int AUX_NT = 2;
+__device__ __forceinline__ rsrc_t mk_rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0,
+                                             (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes),
+                                             0x00020000);
+}
+__device__ __forceinline__ f4 ld16_sc1(rsrc_t r, unsigned byteoff) {
+    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byteoff, 0, AUX_SC1));
+}
+__device__ __forceinline__ void st16_sc1(rsrc_t r, unsigned byteoff, f4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, (int)byteoff, 0, AUX_SC1);
+}
+__device__ __forceinline__ unsigned ldu(rsrc_t r, unsigned voff, int soff) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0);
+}
+typedef __attribute__((address_space(1))) unsigned gu32;
+__device__ __forceinline__ unsigned flag_load(unsigned* p) {
+    return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flag_store(unsigned* p, unsigned v) {
+    __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Workgroup barrier that orders LDS only: __syncthreads() would also wait for every outstanding global
+// load and store, which is exactly the latency the cross-phase prefetches hide.
+__device__ __forceinline__ void wg_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---------------------------------------------------------------------------------------------
+// prep: u8 image [h][w] -> (value, x-derivative) half2 plane [h][w+2] with sentinel columns.
+// grid (ceil((w+2)/256), h, nimages)            (x_derivativeOnGPU costVolume.cu:358-381)
+// ---------------------------------------------------------------------------------------------
+struct PrepArgs {
+    const uint8_t* I[2];
+    fg_t* FG[2];
+};
+
+__global__ void k_v4_prep(PrepArgs pa, int w, int h) {
+    const uint8_t* __restrict__ I = pa.I[blockIdx.z];
+    fg_t* __restrict__ FG = pa.FG[blockIdx.z];
+    const int xp = blockIdx.x * blockDim.x + threadIdx.x;   // padded column
+    const int y = blockIdx.y;
+    if (xp >= w + 2) return;
+    const int x = xp - 1;
+    float f = 60000.0f, g = 60000.0f;
+    if (x >= 0 && x < w) {
+        const uint8_t* row = I + (size_t)y * w;
+        f = 1.0f * (float)(int)row[x];
+        int c1, c2;
+        if (x - 1 >= 0 && x + 1 < w) { c1 = row[x + 1]; c2 = row[x - 1]; }
+        else if (x + 1 >= w)         { c1 = row[x];     c2 = row[x - 1]; }
+        else                         { c1 = row[x + 1]; c2 = row[x];     }
+        g = 1.0f * (float)(c2 - c1) / 2;
+    }
+    fg_t v;
+    v.x = (_Float16)f;
+    v.y = (_Float16)g;
+    FG[(size_t)y * (w + 2) + xp] = v;
+}
+
+// Hand-off record of one iteration (per parity and slice-view), written and read in 16-byte units:
+//   [0, BH)              stage-1 row carries of band i        (float2 per row)
+//   [BH, 2 BH)           stage-2 row carries of band i-1
+//   [2 BH, 2 BH + BH*HP) last 2R+1 columns of the stage-2 integral of band i-1, HP = 20 float2 per row
+constexpr int HP = HWMAX + 1;
+constexpr int REC_F2 = 2 * BH + BH * HP;          // float2 per record
+constexpr int REC_U = REC_F2 / 2;                 // 16-byte units per record: one per thread
+static_assert(REC_U <= NT && HP % 2 == 0 && BH % 2 == 0, "one 16-byte hand-off unit per thread");
+
+// Diagnostic build only (-DSMX_V4_STAMPS=<item>): every wave of one work item records the shader clock
+// at its phase boundaries; the product build contains no stamp.
+#ifdef SMX_V4_STAMPS
+constexpr int STAMP_SLOTS = 5 * 64;
+__device__ unsigned long long g_stamps[NWAVE * STAMP_SLOTS];
+#define V4_STAMP(n)                                                                       \
+    do {                                                                                  \
+        if (item == SMX_V4_STAMPS && lane == 0 && i * 5 + (n) < STAMP_SLOTS)               \
+            g_stamps[wave * STAMP_SLOTS + i * 5 + (n)] = __builtin_amdgcn_s_memtime();     \
+    } while (0)
+#else
+#define V4_STAMP(n) ((void)0)
+#endif
+#ifdef SMX_V4_ITEMLOG
+constexpr int ITEMLOG_MAX = 1 << 16;
+__device__ unsigned long long g_itemlog[3 * ITEMLOG_MAX];
+#endif
+
+constexpr unsigned FLAG_DONE = 0x7fffffffu;
+
+// RT: compile-time box radius (RMAX) or -1 = the radius of the call (A.R <= RMAX)
+template <int SRC, int RT>
+__global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
+    __shared__ __attribute__((aligned(16))) f2 ring1[RR * PITCH];   // stage-1 row y at ring row y mod RR
+    __shared__ __attribute__((aligned(16))) f2 ring2[RR * PITCH];   // a/b row y at ring row (y + R) mod RR
+    __shared__ __attribute__((aligned(16))) f2 cin[2][BH];          // row carries in : stage -> rows of the band
+    __shared__ __attribute__((aligned(16))) f2 cout[2][BH];         // row carries out
+    __shared__ float rcp_s[HWMAX * HWMAX + 1];                      // RN(1/area)
+    __shared__ int s_item, s_next;
+    __shared__ unsigned s_seen;                                     // last value read from the left neighbour's flag
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = A.w, h = A.h, K = A.K, NI = A.NI, nsv = A.nsv;
+    const int R = RT >= 0 ? RT : A.R;
+    const int HW = 2 * R + 1, TW = OW + HW;
+    const CostConst cc = A.cc;
+    const f2 ident = {-0.0f, -0.0f};            // exact additive identity: v + (-0) == v
+    if (tid <= HWMAX * HWMAX) rcp_s[tid] = kRcp.v[tid];
+
+    // this thread's 16-byte unit of a hand-off record
+    const bool hu_on = tid < REC_U;
+    int hu_r = 0, hu_c = 0;                     // halo units: row of the band, first of the two columns
+    if (tid >= BH) {
+        const int u = tid - BH;
+        hu_r = u / (HP / 2);
+        hu_c = (u - hu_r * (HP / 2)) * 2;
+    }
+    // row-scan lanes: each 32-lane group (the unit of LDS banking for dword accesses) takes half of the rows
+    // with both components, lanes 0-15 / 16-31 = first / second component: 16 distinct even + 16 distinct
+    // odd banks (row stride 170 dwords = 10 mod 32)
+    const int srow = (lane & 15) + 16 * (lane >> 5), scomp = (lane >> 4) & 1;
+
+    if (tid == 0) s_item = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        wg_barrier();
+        const int item = s_item;
+        if (item >= A.nitems) break;
+#ifdef SMX_V4_ITEMLOG
+        if (tid == 0 && item < ITEMLOG_MAX) {
+            g_itemlog[3 * item] = __builtin_amdgcn_s_memrealtime();
+            g_itemlog[3 * item + 2] = blockIdx.x;
+        }
+#endif
+        const int k = item / nsv;
+        const int sv = item - k * nsv;
+        const int view = sv / A.nslices;
+        const int slice = sv - view * A.nslices;
+        const View& V = A.v[view];
+        const int xs = k * OW;
+        const int cs1 = xs - R - 1;             // image column of ring-1 column 0
+        const int cs2 = xs - HW;                // image column of ring-2 column 0
+        const bool pred = k > 0, succ = k + 1 < K;
+        const int d = V.d0 + slice;
+        unsigned* const myflag = A.flags + (size_t)sv * K + k;
+        const size_t recs = (size_t)NI * REC_F2;      // float2 per (parity, slice-view)
+        const rsrc_t r_in = mk_rsrc(A.hand + ((size_t)((k - 1) & 1) * nsv + sv) * recs, recs * 8);
+        const rsrc_t r_out = mk_rsrc(A.hand + ((size_t)(k & 1) * nsv + sv) * recs, recs * 8);
+
+        // Every global access of the LANE = COLUMN phases is a buffer instruction: per-lane byte offset fixed
+        // for the item + wave-uniform row offset in a scalar register, no 64-bit address arithmetic.  A lane
+        // whose column lies outside the image carries the offset OOB, which is beyond every plane: its loads
+        // return 0 and its stores are dropped by the range check.
+        constexpr unsigned OOB = 0x80000000u;
+        const unsigned fgw4 = ((unsigned)w + 2u) * 4u, w4 = (unsigned)w * 4u;
+        const unsigned pitch2 = SRC == SRC_IMG ? fgw4 : w4;      // row pitch of the second stage-1 input
+        const size_t plane = (size_t)h * w;
+        const rsrc_t r_fg1 = mk_rsrc(V.FG1, (size_t)h * fgw4);
+        const rsrc_t r_in2 = SRC == SRC_IMG ? mk_rsrc(V.FG2, (size_t)h * fgw4)
+                                            : mk_rsrc(V.cost + (size_t)slice * plane, plane * 4);
+        const rsrc_t r_ga = mk_rsrc(V.mean, plane * 4);
+        const rsrc_t r_gb = mk_rsrc(V.cinv, plane * 4);
+        const rsrc_t r_q = mk_rsrc(V.q + (size_t)slice * plane, plane * 4);
+
+        // per-lane window geometry in x: fixed for the whole item
+        struct Geo { int jmax, jmin, xcw; bool hx; };
+        unsigned vq, vg;                     // byte offset of this lane's q column / a_k, b_k column in a row
+        Geo g1, g2;
+        {
+            auto mkgeo = [&](int x, int cs, unsigned& off4) {
+                Geo g;
+                const bool xin = x >= 0 && x < w;
+                const int xc = min(max(x, 0), w - 1);
+                const int xmax = min(w - 1, xc + R), xmn = xc - R - 1;
+                g.hx = xmn >= 0;
+                g.xcw = xmax - (g.hx ? xmn : -1);
+                g.jmax = min(max(xmax - cs, 0), TW - 1);
+                g.jmin = min(max(xmn - cs, 0), TW - 1);
+                off4 = xin ? (unsigned)xc * 4u : OOB;
+                return g;
+            };
+            g1 = mkgeo(xs + lane, cs1, vg);
+            g2 = mkgeo(xs - R + lane, cs2, vq);
+        }
+        // all 64 windows of the strip unclipped in x: no selects, one area
+        const bool xint1 = xs - R - 1 >= 0 && xs + OW - 1 + R <= w - 1;
+        const bool xint2 = xs - 2 * R - 1 >= 0 && xs + OW - 1 <= w - 1;
+        const float area_full = (float)(HW * HW), ra_full = rcp_s[HW * HW];
+
+        // stage-1 input cells of this lane, fixed for the item: rows 4 wave + t at ring column `lane` (cells
+        // 0..3) and rows 4 wave + 2e + (lane >> 5) at ring column 64 + (lane & 31) (cells 4, 5).  Columns are
+        // clamped into the image instead of predicated: cells outside it are written but never accumulated.
+        const int rsel = lane >> 5;
+        const bool e2_ok = (lane & 31) < HW;
+        unsigned in1a, in1b, in2a, in2b;     // byte offsets inside a row: cells 0..3 and cells 4, 5; first / second input
+        {
+            auto cell = [&](int j, unsigned& o1, unsigned& o2) {
+                const int c = min(max(cs1 + j, 0), w - 1);
+                o1 = (unsigned)(c + 1) * 4u;
+                if (SRC == SRC_IMG) {
+                    int xx = c + d;
+                    xx = xx < -1 ? -1 : (xx > w ? w : xx);   // sentinel columns
+                    o2 = (unsigned)(xx + 1) * 4u;
+                } else {
+                    o2 = (unsigned)c * 4u;
+                }
+            };
+            cell(lane, in1a, in2a);
+            cell(64 + (lane & 31), in1b, in2b);
+        }
+        const int jlo1 = max(0, -cs1), jhi1 = min(TW, w - cs1);   // ring-1 columns inside the image
+        const int jlo2 = HW, jhi2 = min(TW, w - cs2);             // new ring-2 columns inside the image
+
+        uint32_t ua[6], ub[6];               // raw stage-1 inputs of the next band
+        float ga[RPW], gb[RPW];              // mean_I, 1/(var+eps) of the a/b rows of the next X phase
+        uint32_t Iraw[RPW];                  // raw (value, gradient) halves of the q rows of the next X phase
+        f2 abreg[RPW];                       // a_k, b_k of this wave's rows, written to ring 2 in the next W phase
+        f4 hreg = {0, 0, 0, 0};              // this thread's unit of the left neighbour's next record
+        bool have_pref = false;
+        unsigned seen = 0;
+#pragma unroll
+        for (int t = 0; t < RPW; ++t) { abreg[t] = ident; }
+
+        // loads for iteration ib: stage-1 inputs of band ib, guidance of its a/b rows, guidance image of its q
+        // rows.  Rows are clamped into the image: every load is issued whether its row exists or not.
+        auto issue_next = [&](int ib) {
+            const int y0 = BH * ib + RPW * wave;
+#pragma unroll
+            for (int t = 0; t < RPW; ++t) {
+                const int ye = min(y0 + t, h - 1);
+                ua[t] = ldu(r_fg1, in1a, ye * (int)fgw4);
+                ub[t] = ldu(r_in2, in2a, ye * (int)pitch2);
+            }
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int ye0 = min(y0 + 2 * e, h - 1), ye1 = min(y0 + 2 * e + 1, h - 1);
+                const unsigned dy = (unsigned)(ye1 - ye0);   // 1, or 0 on the last image row
+                ua[4 + e] = ldu(r_fg1, in1b + (rsel ? dy * fgw4 : 0u), ye0 * (int)fgw4);
+                ub[4 + e] = ldu(r_in2, in2b + (rsel ? dy * pitch2 : 0u), ye0 * (int)pitch2);
+            }
+            const int ya0 = BH * ib - R + RPW * wave;
+#pragma unroll
+            for (int t = 0; t < RPW; ++t) {
+                const int y = min(max(ya0 + t, 0), h - 1);
+                ga[t] = __builtin_bit_cast(float, ldu(r_ga, vg, y * (int)w4));
+                gb[t] = __builtin_bit_cast(float, ldu(r_gb, vg, y * (int)w4));
+            }
+            const int yq0 = BH * (ib - 1) - 2 * R + RPW * wave;
+#pragma unroll
+            for (int t = 0; t < RPW; ++t) {
+                const int y = min(max(yq0 + t, 0), h - 1);
+                Iraw[t] = ldu(r_fg1, vq, y * (int)fgw4 + 4);     // column + 1 in the padded plane
+            }
+        };
+
+        // bounded wait for the left neighbour's flag >= need (thread 0 only); result -> s_seen
+        auto spin_pred = [&](unsigned need) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                const unsigned f = flag_load(myflag - 1);
+                if (f >= need) { s_seen = f; break; }
+                __builtin_amdgcn_s_sleep(4);
+                // give up after 2 s (100 MHz counter) or as soon as any workgroup has given up; the call then
+                // reports SMX_E_HIP through smx_dev_agg_status
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull || flag_load(A.status) != 0u) {
+                    flag_store(A.status, 1u + (unsigned)item);
+                    s_seen = FLAG_DONE;
+                    break;
+                }
+            }
+        };
+
+        // ---- row scan of one band: this lane = one component of one row ------------------------------------
+        auto rowscan = [&](f2* ring, int st, int rbase, int yband, int jlo, int jhi, bool full, auto NCOL) {
+            constexpr int NC = decltype(NCOL)::value;      // columns of the unrolled form
+            const int y = yband + srow;
+            if (y < 0 || y >= h || jhi <= jlo) return;
+            int rr = rbase + srow;
+            rr = rr >= RR ? rr - RR : rr;
+            float acc = pred ? ((const float*)&cin[st][srow])[scomp] : -0.0f;
+            float* row = (float*)(ring + rr * PITCH) + scomp;   // column c of this component: row[2 c]
+            if (full) {
+                // the common case: NC columns from jlo, fully unrolled so that every LDS wait is a counted one;
+                // the reads run one batch of 8 columns ahead of the adds
+                float* r0 = row + 2 * jlo;
+                constexpr int NBATCH = NC / 8;
+                float v[2][8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[0][t] = r0[2 * t];
+#pragma unroll
+                for (int bt = 0; bt < NBATCH; ++bt) {
+                    if (bt + 1 < NBATCH) {
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) v[(bt + 1) & 1][t] = r0[2 * (8 * (bt + 1) + t)];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        acc = v[bt & 1][t] + acc;
+                        r0[2 * (8 * bt + t)] = acc;
+                        if (st == 0 && 8 * bt + t == OW - 1) ((float*)&cout[0][srow])[scomp] = acc;
+                    }
+                }
+#pragma unroll
+                for (int c = 8 * NBATCH; c < NC; ++c) {
+                    acc = r0[2 * c] + acc;
+                    r0[2 * c] = acc;
+                }
+                if (st == 1) ((float*)&cout[1][srow])[scomp] = acc;
+                return;
+            }
+            // general strip: batches of 8 columns, ping-pong; the reads of the next batch are always issued
+            // (past the end they fetch bytes nobody uses: LDS reads cannot fault)
+            int j = jlo;
+            const int nb8 = (jhi - j) >> 3;
+            float va[8], vb[8];
+            auto rd = [&](float (&v)[8], int c) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = row[2 * (c + t)];
+            };
+            auto run = [&](const float (&v)[8], int c) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    acc = v[t] + acc;
+                    row[2 * (c + t)] = acc;
+                }
+            };
+            if (nb8 > 0) rd(va, j);
+            int b = 0;
+            for (; b + 2 <= nb8; b += 2) {
+                rd(vb, j + 8);
+                run(va, j);
+                rd(va, j + 16);
+                run(vb, j + 8);
+                j += 16;
+            }
+            if (b < nb8) {
+                run(va, j);
+                j += 8;
+            }
+            for (; j < jhi; ++j) {
+                acc = row[2 * j] + acc;
+                row[2 * j] = acc;
+            }
+            // running row sum left of the next strip's first column (stage 1: ring column OW-1; stage 2: the last one)
+            if (st == 0) { if (OW - 1 >= jlo && OW - 1 < jhi) ((float*)&cout[0][srow])[scomp] = row[2 * (OW - 1)]; }
+            else ((float*)&cout[1][srow])[scomp] = acc;
+        };
+
+        // ---- column scan of one band for the ring column of this lane (LANE = COLUMN) ----------------------
+        // rows yband + t at ring rows (rbase + t) mod RR; groups of four rows never wrap (RR % 4 == 0)
+        auto colscan = [&](f2* ring, int col, int rbase, int yband, f2& S) {
+            f2* const pc = ring + col;
+            if (yband >= 0 && yband + BH <= h) {
+                // full band: the reads of the next group of four rows are issued before the adds of this one
+                f2 v[2][4];
+                int rr = rbase;
+                f2* p = pc + rr * PITCH;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) v[0][t] = p[t * PITCH];
+#pragma unroll
+                for (int g = 0; g < BH / 4; ++g) {
+                    int rn = rr + 4;
+                    rn = rn >= RR ? rn - RR : rn;
+                    f2* pn = pc + rn * PITCH;
+                    if (g + 1 < BH / 4) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[(g + 1) & 1][t] = pn[t * PITCH];
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        S = v[g & 1][t] + S;
+                        p[t * PITCH] = S;
+                    }
+                    rr = rn;
+                    p = pn;
+                }
+                return;
+            }
+            for (int t = 0; t < BH; ++t) {
+                const int y = yband + t;
+                if (y < 0 || y >= h) continue;
+                int rr = rbase + t;
+                rr = rr >= RR ? rr - RR : rr;
+                S = pc[rr * PITCH] + S;
+                pc[rr * PITCH] = S;
+            }
+        };
+
+        // ---- box means of this wave's four rows (computeBoxFilterOnGPU guidedFilter.cu:305-318: S11 - S10 -
+        // S01 + S00 in that order, then a true division by the window area) ---------------------------------
+        // fast form: every window of the band is unclipped in x and y.  rbase = ring row of the band's first
+        // bottom tap row (the top tap row is 2R+1 ring rows above it).
+        auto box4_fast = [&](const f2* ring, int rbase, f2 (&m)[RPW]) {
+            int rb0 = rbase + RPW * wave;
+            rb0 = rb0 >= RR ? rb0 - RR : rb0;
+            f2 s11[RPW], s10[RPW], s01[RPW], s00[RPW], val[RPW];
+#pragma unroll
+            for (int t = 0; t < RPW; ++t) {
+                int rt = rb0 + t - HW;
+                rt = rt < 0 ? rt + RR : rt;
+                const f2* pb = ring + (rb0 + t) * PITCH + lane;
+                const f2* pt = ring + rt * PITCH + lane;
+                s11[t] = pb[HW]; s10[t] = pb[0];
+                s01[t] = pt[HW]; s00[t] = pt[0];
+            }
+            bool slow = false;
+#pragma unroll
+            for (int t = 0; t < RPW; ++t) {
+                f2 v = s11[t] - s10[t];
+                v = v - s01[t];
+                v = v + s00[t];
+                val[t] = v;
+                m[t].x = div_small_int(v.x, area_full, ra_full);
+                m[t].y = div_small_int(v.y, area_full, ra_full);
+                slow = slow || div_needs_exact(v.x) || div_needs_exact(v.y);
+            }
+            if (__any(slow)) {
+                asm volatile("; exact-division slow path");   // keep this a real (rare) wave-uniform branch
+#pragma unroll
+                for (int t = 0; t < RPW; ++t) {
+                    m[t].x = 1.0f * val[t].x / area_full;
+                    m[t].y = 1.0f * val[t].y / area_full;
+                }
+            }
+        };
+        // general form: windows clipped at the image borders; rows y0 + t that do not exist are skipped
+        // (ok[t] = false).  shift = 0 (ring 1) or R (ring 2).
+        auto box4_gen = [&](const f2* ring, int shift, const Geo& g, bool xint, int y0, f2 (&m)[RPW], bool (&ok)[RPW]) {
+            const f2* const pmax = ring + g.jmax;
+            const f2* const pmin = ring + g.jmin;
+            const bool left = xint || g.hx;
+#pragma unroll
+            for (int t = 0; t < RPW; ++t) {
+                const int y = y0 + t;
+                ok[t] = y >= 0 && y < h;
+                m[t] = ident;
+                if (!ok[t]) continue;                       // wave-uniform
+                const int ymax = min(h - 1, y + R);
+                const int ymin = y - R - 1;
+                const bool hy = ymin >= 0;
+                const int ych = ymax - (hy ? ymin : -1);
+                const int o1 = ((ymax + shift) % RR) * PITCH, o0 = (((hy ? ymin : 0) + shift) % RR) * PITCH;
+                const f2 s11 = pmax[o1], s10 = pmin[o1], s01 = pmax[o0], s00 = pmin[o0];
+                const int ai = (xint ? HW : g.xcw) * ych;
+                const float area = (float)ai, ra = rcp_s[ai];
+                f2 v = s11;
+                f2 u = v - s10;
+                v = left ? u : v;
+                u = v - s01;
+                v = hy ? u : v;
+                u = v + s00;
+                v = (hy && left) ? u : v;
+                m[t].x = div_small_int(v.x, area, ra);
+                m[t].y = div_small_int(v.y, area, ra);
+                if (__any(div_needs_exact(v.x) || div_needs_exact(v.y))) {
+                    asm volatile("; exact-division slow path");
+                    m[t].x = 1.0f * v.x / area;
+                    m[t].y = 1.0f * v.y / area;
+                }
+            }
+        };
+
+        // ===================================== the band loop ==============================================
+        // prologue: loads of iteration 0; the left neighbour's record 0
+        issue_next(0);
+        if (pred) {
+            if (tid == 0) spin_pred(1u);
+            wg_barrier();
+            seen = s_seen;
+            if (hu_on) hreg = ld16_sc1(r_in, (unsigned)(tid * 16));
+            have_pref = true;
+        }
+        f2 S1 = ident, S2 = ident;          // running column sums of this lane's column (waves 0, 1 / wave 2)
+        int rb = 0, rbp = 0;                // ring row of the first row of band i / band i-1 (both rings)
+        for (int i = 0; i < NI; ++i) {
+            // ------------------------------------ W(i) --------------------------------------------------
+            V4_STAMP(0);
+            {
+                int rw = rb + RPW * wave;
+                rw = rw >= RR ? rw - RR : rw;
+                f2* const rb1 = ring1 + rw * PITCH;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    const fg_t q1 = __builtin_bit_cast(fg_t, ua[e]);
+                    f2 v;
+                    if (SRC == SRC_IMG) {
+                        v = cost_pair(q1, __builtin_bit_cast(fg_t, ub[e]), cc);
+                    } else {
+                        v.x = __builtin_bit_cast(float, ub[e]);   // copyFromBigToLittleOnGPU guidedFilter.cu:198
+                        v.y = (float)q1.x * v.x;                  // pixelMultOnGPU(d_im, d_p) :209
+                    }
+                    if (e < 4) rb1[e * PITCH + lane] = v;
+                    else if (e2_ok) rb1[(2 * (e - 4) + rsel) * PITCH + 64 + (lane & 31)] = v;
+                }
+                if (i >= 1) {
+                    int rw2 = rbp + RPW * wave;
+                    rw2 = rw2 >= RR ? rw2 - RR : rw2;
+#pragma unroll
+                    for (int t = 0; t < RPW; ++t) ring2[(rw2 + t) * PITCH + HW + lane] = abreg[t];
+                }
+                if (pred) {
+                    if (!have_pref) {
+                        // the neighbour had not published record i when this item looked: wait for it now
+                        if (tid == 0) spin_pred((unsigned)i + 1u);
+                        wg_barrier();
+                        seen = s_seen;
+                        if (hu_on) hreg = ld16_sc1(r_in, (unsigned)((i * REC_F2) * 8 + tid * 16));
+                    }
+                    if (hu_on) {
+                        if (tid < BH / 2) *(f4*)&cin[0][2 * tid] = hreg;
+                        else if (tid < BH) *(f4*)&cin[1][2 * (tid - BH / 2)] = hreg;
+                        else if (i >= 1 && hu_c < HW) {
+                            int rr = rbp + hu_r;
+                            rr = rr >= RR ? rr - RR : rr;
+                            f2* dst = ring2 + rr * PITCH + hu_c;
+                            dst[0] = (f2){hreg.x, hreg.y};
+                            if (hu_c + 1 < HW) dst[1] = (f2){hreg.z, hreg.w};
+                        }
+                    }
+                    have_pref = false;
+                }
+            }
+            // every wave drains its global accesses here: the record stored in X(i-1) is complete in memory
+            // before the barrier behind which one lane publishes it
+            drain_vmem();
+            wg_barrier();
+            V4_STAMP(1);
+            // ------------------------------------ R(i) --------------------------------------------------
+            if (wave == 0) {
+                if (succ && lane == 0 && i >= 1) flag_store(myflag, (unsigned)i);
+                rowscan(ring1, 0, rb, BH * i, jlo1, jhi1, RT == RMAX && jlo1 == 0 && jhi1 == TWMAX,
+                        std::integral_constant<int, TWMAX>{});
+            } else if (wave == 1) {
+                if (i >= 1)
+                    rowscan(ring2, 1, rbp, BH * (i - 1) - R, jlo2, jhi2, RT == RMAX && jhi2 == TWMAX,
+                            std::integral_constant<int, OW>{});
+            } else if (wave == NWAVE - 1 && lane == 0) {
+                // an otherwise idle lane looks at the left neighbour's flag for the prefetch of record i+1
+                if (pred && seen != FLAG_DONE && seen < (unsigned)i + 2u) s_seen = flag_load(myflag - 1);
+                // ticket of the next item, one iteration before the end
+                if (i == NI - 1)
+                    s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            wg_barrier();
+            V4_STAMP(2);
+            // ------------------------------------ C(i) --------------------------------------------------
+            if (wave == 0) {
+                colscan(ring1, lane, rb, BH * i, S1);
+            } else if (wave == 1) {
+                if (lane < HW) colscan(ring1, OW + lane, rb, BH * i, S1);
+            } else if (wave == 2) {
+                if (i >= 1) colscan(ring2, HW + lane, rbp, BH * (i - 1) - R, S2);
+            }
+            wg_barrier();
+            V4_STAMP(3);
+            // ------------------------------------ X(i) --------------------------------------------------
+            seen = s_seen;
+            if (succ && hu_on) {
+                // record i: row carries of this iteration's row scans, last 2R+1 columns of the stage-2 integral
+                f4 v;
+                if (tid < BH / 2) v = *(const f4*)&cout[0][2 * tid];
+                else if (tid < BH) v = *(const f4*)&cout[1][2 * (tid - BH / 2)];
+                else {
+                    int rr = rbp + hu_r;
+                    rr = rr >= RR ? rr - RR : rr;
+                    const f2* p = ring2 + rr * PITCH + OW + hu_c;
+                    const f2 a = p[0], b = p[1];
+                    v = (f4){a.x, a.y, b.x, b.y};
+                }
+                st16_sc1(r_out, (unsigned)((i * REC_F2) * 8 + tid * 16), v);
+            }
+            if (i >= 1) {
+                // box means of stage 2 -> q rows [BH (i-1) - 2R, BH i - 2R)
+                const int yq0 = BH * (i - 1) - 2 * R + RPW * wave;
+                f2 m[RPW];
+                bool ok[RPW];
+                if (xint2 && BH * (i - 1) - 3 * R - 1 >= 0 && BH * i - R <= h) {
+                    box4_fast(ring2, rbp, m);
+#pragma unroll
+                    for (int t = 0; t < RPW; ++t) ok[t] = true;
+                } else {
+                    box4_gen(ring2, R, g2, xint2, yq0, m, ok);
+                }
+#pragma unroll
+                for (int t = 0; t < RPW; ++t) {
+                    const float Iv = (float)__builtin_bit_cast(fg_t, Iraw[t]).x;
+                    float tq = m[t].x * Iv;            // compute_q guidedFilter.cu:363-369
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tq + m[t].y), r_q, (int)(ok[t] ? vq : OOB),
+                                                          min(max(yq0 + t, 0), h - 1) * (int)w4, AUX_NT);
+                }
+            }
+            {
+                // box means of stage 1 -> a_k, b_k rows [BH i - R, BH i + BH - R)   (compute_ak_and_bk guidedFilter.cu:345-354)
+                const int ya0 = BH * i - R + RPW * wave;
+                f2 m[RPW];
+                bool ok[RPW];
+                if (xint1 && BH * i - 2 * R - 1 >= 0 && BH * i + BH <= h) {
+                    box4_fast(ring1, rb, m);
+                } else {
+                    box4_gen(ring1, 0, g1, xint1, ya0, m, ok);
+                }
+#pragma unroll
+                for (int t = 0; t < RPW; ++t) {
+                    float mm = ga[t] * m[t].x;
+                    float ak = 1.0f * (m[t].y - mm) * gb[t];
+                    float mb2 = 1.0f * ga[t] * ak;
+                    float bk = 1.0f * m[t].x - mb2;
+                    abreg[t] = (f2){ak, bk};
+                }
+            }
+            if (i + 1 < NI) {
+                issue_next(i + 1);
+                // the left neighbour's record i+1, if it has been published already
+                if (pred && (seen == FLAG_DONE || seen >= (unsigned)i + 2u)) {
+                    if (hu_on) hreg = ld16_sc1(r_in, (unsigned)(((i + 1) * REC_F2) * 8 + tid * 16));
+                    have_pref = true;
+                }
+            }
+            V4_STAMP(4);
+            wg_barrier();
+            rbp = rb;
+            rb += BH;
+            rb = rb >= RR ? rb - RR : rb;
+        }
+        // the last record and the last q rows: drained, then published
+        drain_vmem();
+        wg_barrier();
+        if (tid == 0) {
+            if (succ) flag_store(myflag, FLAG_DONE);
+            s_item = s_next;
+        }
+#ifdef SMX_V4_ITEMLOG
+        if (tid == 0 && item < ITEMLOG_MAX) g_itemlog[3 * item + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// WTA over the chunk's q planes [slice][h][w] (dispSelectOnGPU guidedFilter.cu:403-411 in packed-key
+// form).  One lane per pixel; grid (ceil(n/256), nviews)
+// ---------------------------------------------------------------------------------------------
+struct WtaArgs {
+    const float* q[2];
+    int64_t* keys[2];
+};
+
+__global__ __launch_bounds__(256) void k_v4_wta(WtaArgs wa, size_t n, int count, int slice0) {
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= n) return;
+    const float* __restrict__ q = wa.q[blockIdx.y] + id;
+    int64_t* keys = wa.keys[blockIdx.y];
+    int64_t key = keys[id];
+    int z = 0;
+    for (; z + 8 <= count; z += 8) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = __builtin_nontemporal_load(&q[(size_t)(z + t) * n]);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            int64_t kk = pack_key(v[t], (uint32_t)(slice0 + z + t));
+            key = kk < key ? kk : key;
+        }
+    }
+    for (; z < count; ++z) {
+        int64_t kk = pack_key(__builtin_nontemporal_load(&q[(size_t)z * n]), (uint32_t)(slice0 + z));
+        key = kk < key ? kk : key;
+    }
+    keys[id] = key;
+}
+
+// The same with two pixels per lane (8-byte loads).  Needs an even plane size n and 8-byte aligned planes.
+// grid (ceil(n/512), nviews)
+__global__ __launch_bounds__(256) void k_v4_wta2(WtaArgs wa, size_t n, int count, int slice0) {
+    const size_t id = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (id >= n) return;
+    const float* __restrict__ q = wa.q[blockIdx.y] + id;
+    int64_t* keys = wa.keys[blockIdx.y];
+    int64_t k0 = keys[id], k1 = keys[id + 1];
+    int z = 0;
+    for (; z + 8 <= count; z += 8) {
+        f2 v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = __builtin_nontemporal_load((const f2*)&q[(size_t)(z + t) * n]);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int64_t a = pack_key(v[t].x, (uint32_t)(slice0 + z + t)), b = pack_key(v[t].y, (uint32_t)(slice0 + z + t));
+            k0 = a < k0 ? a : k0;
+            k1 = b < k1 ? b : k1;
+        }
+    }
+    for (; z < count; ++z) {
+        const f2 v = __builtin_nontemporal_load((const f2*)&q[(size_t)z * n]);
+        const int64_t a = pack_key(v.x, (uint32_t)(slice0 + z)), b = pack_key(v.y, (uint32_t)(slice0 + z));
+        k0 = a < k0 ? a : k0;
+        k1 = b < k1 ? b : k1;
+    }
+    keys[id] = k0;
+    keys[id + 1] = k1;
+}
+
+}  // namespace v4
+
+// =============================================================================================
+// host orchestration
+// =============================================================================================
+static inline unsigned cdivu4(int64_t a, int64_t b) { return (unsigned)((a + b - 1) / b); }
+
+struct V4Layout {
+    int K, NI;
+    size_t fg;        // floats per image plane (half2 = 4 B per pixel)
+    size_t plane;     // floats per w*h plane
+    size_t sv_hand;   // floats of hand-off records per slice-view (2 parities x NI records)
+};
+
+static V4Layout v4_layout(int w, int h, int R) {
+    V4Layout L;
+    L.K = (w + R + v4::OW - 1) / v4::OW;
+    L.NI = (h - 1 + 2 * R) / v4::BH + 2;     // the q rows of iteration i end at BH i - 2R
+    L.fg = (size_t)(w + 2) * h;
+    L.plane = (size_t)w * h;
+    L.sv_hand = (size_t)2 * L.NI * v4::REC_F2 * 2;   // parity x records x float2
+    return L;
+}
+
+void v4_geometry(int* ow, int* bh) { *ow = v4::OW; *bh = v4::BH; }
+
+bool v4_supported(const smx_params* p) { return p->radius >= 0 && p->radius <= v4::RMAX; }
+
+constexpr size_t V4_CTRL_BYTES = 256;   // ticket (zeroed with the flags before every launch)
+
+static size_t v4_flag_bytes(const V4Layout& L, int nsv) {
+    return align_up(V4_CTRL_BYTES + (size_t)nsv * L.K * sizeof(unsigned), 256);
+}
+
+// bytes for ONE view with `nslices` slices in flight (q planes included)
+size_t v4_workspace_bytes(int w, int h, int nslices) {
+    V4Layout L = v4_layout(w, h, v4::RMAX);
+    size_t b = 256;
+    b += 2 * align_up(L.fg * 4, 256);                               // both image planes (single-view calls too)
+    b += 2 * align_up(L.plane * 4, 256);                            // mean_I, 1/(var+eps)
+    b += 3 * align_up(L.plane * 4, 256);                            // guidance scratch: im, im^2 / S_sq, S_im
+    b += (size_t)nslices * align_up(L.plane * 4, 256);              // q
+    b += align_up((size_t)nslices * L.sv_hand * 4, 256);
+    b += v4_flag_bytes(L, 2 * nslices);                             // control block (shared by both views)
+    return b + 16 * 256;
+}
+
+template <int SRC>
+static int launch_walk4(const v4::Args& a, hipStream_t st) {
+    int dev = 0, ncu = 256;
+    SMX_HIP(hipGetDevice(&dev));
+    SMX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int slots = 2 * ncu;                           // persistent: two workgroups per CU
+    const int grid = a.nitems < slots ? a.nitems : slots;
+    if (a.R == v4::RMAX)
+        hipLaunchKernelGGL((v4::k_v4_walk<SRC, v4::RMAX>), dim3((unsigned)grid), dim3(v4::NT), 0, st, a);
+    else
+        hipLaunchKernelGGL((v4::k_v4_walk<SRC, -1>), dim3((unsigned)grid), dim3(v4::NT), 0, st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+#ifdef SMX_V4_ITEMLOG
+extern "C" __attribute__((visibility("default"))) int smx_debug_read_itemlog(unsigned long long* out, int n) {
+    const int m = 3 * v4::ITEMLOG_MAX;
+    SMX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(v4::g_itemlog), sizeof(unsigned long long) * (n < m ? n : m)));
+    return SMX_OK;
+}
+#endif
+#ifdef SMX_V4_STAMPS
+extern "C" __attribute__((visibility("default"))) int smx_debug_read_stamps(unsigned long long* out, int n) {
+    const int m = v4::NWAVE * v4::STAMP_SLOTS;
+    SMX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(v4::g_stamps), sizeof(unsigned long long) * (n < m ? n : m)));
+    return m;
+}
+#endif
+
+// status word of the last fused aggregation that used this workspace (0 = ok)
+int v4_read_status(const void* d_ws, unsigned* out) {
+    const char* base = (const char*)align_up((size_t)d_ws, 256);
+    SMX_HIP(hipMemcpy(out, base, sizeof(unsigned), hipMemcpyDeviceToHost));
+    return SMX_OK;
+}
+
+// Aggregation + WTA of slices [s_begin, s_end) of `nviews` (1 or 2) views.  View v uses d_guide[v]
+// as guidance; its cost slices are d_cost[v] (materialised, slice s at (s - s_begin)*w*h) or, when
+// d_cost[v] == NULL, are built on the fly against d_guide[v ^ 1] (nviews == 2) / d_other[0].
+int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
+                 const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
+                 const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
+                 uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
+                 hipStream_t st, int* launches) {
+    const int R = p->radius;
+    const V4Layout L = v4_layout(w, h, R);
+    const bool use_cost = d_cost && d_cost[0];
+    // every plane is addressed through 32-bit buffer offsets, with 0x80000000 as "outside the image"
+    if ((size_t)h * ((size_t)w + 2) * 4 >= 0x80000000ull)
+        return fail(SMX_E_ARG, "aggregate_v4: an image plane of %d x %d exceeds 2 GiB", w, h);
+    if (use_cost && nviews == 2 && !d_cost[1])
+        return fail(SMX_E_ARG, "aggregate_v4: both views need a cost volume or none");
+    char* base = (char*)align_up((size_t)d_ws, 256);
+    size_t avail = ws_bytes > (size_t)(base - (char*)d_ws) ? ws_bytes - (size_t)(base - (char*)d_ws) : 0;
+    bool oom = false;
+    auto carve = [&](size_t bytes) {
+        char* r = base;
+        size_t b = align_up(bytes, 256);
+        if (b > avail) { oom = true; b = avail; }
+        base += b;
+        avail -= b;
+        return (void*)r;
+    };
+    // first 256 B: status word of the call (smx_dev_agg_status)
+    unsigned* status = (unsigned*)carve(256);
+    if (oom) return fail(SMX_E_WS, "aggregate_v4: workspace too small");
+    SMX_HIP(hipMemsetAsync(status, 0, 256, st));
+    // fixed part: image planes, guidance statistics, guidance scratch
+    v4::fg_t* FG[2];
+    float *meanI[2], *cinv[2], *gs[3];
+    for (int i = 0; i < 2; ++i) FG[i] = (v4::fg_t*)carve(L.fg * 4);
+    for (int v = 0; v < nviews; ++v) { meanI[v] = (float*)carve(L.plane * 4); cinv[v] = (float*)carve(L.plane * 4); }
+    for (int i = 0; i < 3; ++i) gs[i] = (float*)carve(L.plane * 4);
+    const int total = s_end - s_begin;
+    // per slice-view: q plane (unless the caller's volume is written directly) + records + flags
+    const bool own_q = !(d_agg && d_agg[0]);
+    const size_t per_sv = (own_q ? align_up(L.plane * 4, 256) : 0) + L.sv_hand * 4 +
+                          (size_t)L.K * sizeof(unsigned);
+    size_t fit = avail > 8 * 256 + V4_CTRL_BYTES ? (avail - 8 * 256 - V4_CTRL_BYTES) / (per_sv * nviews) : 0;
+    if (oom || (fit < 1 && total > 0))
+        return fail(SMX_E_WS, "aggregate_v4: workspace %zu B too small (need >= %zu B per view)",
+                    ws_bytes, v4_workspace_bytes(w, h, 1));
+    int chunk = fit > (size_t)total ? total : (int)fit;
+    if (chunk < 1) chunk = 1;
+    const int nsv_max = chunk * nviews;
+    float* qbuf[2] = {nullptr, nullptr};
+    if (own_q)
+        for (int v = 0; v < nviews; ++v) qbuf[v] = (float*)carve((size_t)chunk * align_up(L.plane * 4, 256));
+    v4::f2* hand = (v4::f2*)carve((size_t)nsv_max * L.sv_hand * 4);
+    char* ctrl = (char*)carve(v4_flag_bytes(L, nsv_max));
+    if (oom) return fail(SMX_E_WS, "aggregate_v4: workspace carve overflow");
+    int nl = 0, rc;
+
+    v4::PrepArgs pa;
+    pa.I[0] = d_guide[0];
+    pa.I[1] = nviews == 2 ? d_guide[1] : (d_other ? d_other[0] : nullptr);
+    pa.FG[0] = FG[0]; pa.FG[1] = FG[1];
+    const int nimg = pa.I[1] ? 2 : 1;
+    hipLaunchKernelGGL(v4::k_v4_prep, dim3(cdivu4(w + 2, 256), h, nimg), dim3(256), 0, st, pa, w, h);
+    SMX_HIP(hipGetLastError());
+    ++nl;
+
+    // ---- guidance statistics (guidedFilter.cu:58-123): mean_I, 1/(var_I + eps), optional u8 mean image
+    for (int v = 0; v < nviews; ++v) {
+        if ((rc = launch_guid_prep(d_guide[v], gs[0], gs[1], (int64_t)L.plane, st))) return rc;
+        if ((rc = launch_integral(2, gs[0], gs[1], gs[2], gs[1], w, h, 1, st))) return rc;
+        if ((rc = launch_guid_finish(p, gs[2], gs[1], meanI[v], cinv[v], d_mean_u8 ? d_mean_u8[v] : nullptr, w, h, st)))
+            return rc;
+        nl += 4;
+    }
+
+    v4::Args a0;
+    memset(&a0, 0, sizeof(a0));
+    a0.w = w; a0.h = h; a0.R = R; a0.K = L.K; a0.NI = L.NI;
+    a0.cc = make_cost_const(p);
+    for (int v = 0; v < nviews; ++v) {
+        a0.v[v].FG1 = FG[v]; a0.v[v].FG2 = FG[v ^ 1];
+        a0.v[v].mean = meanI[v]; a0.v[v].cinv = cinv[v];
+    }
+    for (int s0 = s_begin; s0 < s_end; s0 += chunk) {
+        const int cnt = (s_end - s0) < chunk ? (s_end - s0) : chunk;
+        v4::Args a = a0;
+        v4::WtaArgs wa;
+        for (int v = 0; v < 2; ++v) {
+            const int vv = v < nviews ? v : 0;
+            float* qv = own_q ? qbuf[vv] : d_agg[vv] + (size_t)(s0 - s_begin) * L.plane;
+            if (v < nviews) {
+                a.v[v].q = qv;
+                a.v[v].d0 = dmin[v] + s0;
+                a.v[v].cost = use_cost ? d_cost[v] + (size_t)(s0 - s_begin) * L.plane : nullptr;
+            }
+            wa.q[v] = qv;
+            wa.keys[v] = d_keys[vv];
+        }
+        a.nslices = cnt; a.nsv = cnt * nviews;
+        a.nitems = a.nsv * L.K;
+        a.hand = hand;
+        a.ticket = (unsigned*)ctrl; a.status = status;
+        a.flags = (unsigned*)(ctrl + V4_CTRL_BYTES);
+        SMX_HIP(hipMemsetAsync(ctrl, 0, v4_flag_bytes(L, a.nsv), st));
+        rc = use_cost ? launch_walk4<v4::SRC_COST>(a, st) : launch_walk4<v4::SRC_IMG>(a, st);
+        if (rc) return rc;
+        bool al8 = L.plane % 2 == 0;
+        for (int v = 0; v < nviews; ++v) al8 = al8 && ((uintptr_t)wa.q[v] & 7) == 0;
+        if (al8)
+            hipLaunchKernelGGL(v4::k_v4_wta2, dim3(cdivu4((int64_t)L.plane, 512), nviews), dim3(256), 0, st, wa,
+                               L.plane, cnt, s0);
+        else
+            hipLaunchKernelGGL(v4::k_v4_wta, dim3(cdivu4((int64_t)L.plane, 256), nviews), dim3(256), 0, st, wa,
+                               L.plane, cnt, s0);
+        SMX_HIP(hipGetLastError());
+        nl += 3;
+    }
+    if (launches) *launches = nl;
+    return SMX_OK;
+}
+
+}  // namespace smx

@@ -14,7 +14,7 @@ static thread_local bool g_timing = false;
 static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static thread_local bool g_ev_valid = false;
 static thread_local int g_launches = 0;
-static int g_agg_path = 0;                 // 0 auto, 1 force multi-kernel, 2 force fused
+static int g_agg_path = 0;                 // 0 auto, 1 force multi-kernel, 2 force fused, 3 force the round-2 fused kernel
 static thread_local int g_last_path = 0;
 
 // smx_agg_v3.hip
@@ -28,6 +28,29 @@ int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
 
 int v3_read_status(const void* d_ws, unsigned* out);
 void v3_geometry(int* ow, int* bh);
+
+// smx_agg_v4.hip
+bool v4_supported(const smx_params* p);
+size_t v4_workspace_bytes(int w, int h, int nslices);
+int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
+                 const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
+                 const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
+                 uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
+                 hipStream_t st, int* launches);
+void v4_geometry(int* ow, int* bh);
+
+// the fused aggregation: smx_agg_v4.hip, or its predecessor smx_agg_v3.hip when path 3 is forced (A/B timing)
+static int aggregate_fused(const smx_params* p, int nviews, const uint8_t* const* d_guide,
+                           const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
+                           const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
+                           uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
+                           hipStream_t st, int* launches) {
+    if (g_agg_path == 3)
+        return aggregate_v3(p, nviews, d_guide, d_other, d_cost, w, h, dmin, s_begin, s_end, d_keys, d_mean_u8,
+                            d_agg, d_ws, ws_bytes, st, launches);
+    return aggregate_v4(p, nviews, d_guide, d_other, d_cost, w, h, dmin, s_begin, s_end, d_keys, d_mean_u8,
+                        d_agg, d_ws, ws_bytes, st, launches);
+}
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -130,11 +153,13 @@ size_t smx_agg_workspace_bytes(int w, int h, int nslices) {
     // v1 path: guidance im, mean_im, cinv, S_im, S_sq ; per slice in flight: cost, T0, T1, A, B
     const size_t v1 = plane_bytes(w, h) * (5 + 5 * (size_t)nslices) + 2 * WS_ALIGN;
     const size_t v3b = v3_workspace_bytes(w, h, nslices);
-    return v1 > v3b ? v1 : v3b;
+    const size_t v4b = v4_workspace_bytes(w, h, nslices);
+    const size_t f = v3b > v4b ? v3b : v4b;
+    return v1 > f ? v1 : f;
 }
 
 int smx_set_agg_path(int path) {
-    if (path < 0 || path > 2) return fail(SMX_E_ARG, "smx_set_agg_path: path must be 0, 1 or 2");
+    if (path < 0 || path > 3) return fail(SMX_E_ARG, "smx_set_agg_path: path must be 0, 1, 2 or 3");
     g_agg_path = path;
     return SMX_OK;
 }
@@ -143,7 +168,8 @@ int smx_last_agg_path(void) { return g_last_path; }
 
 int smx_agg_geometry(int radius, int* strip_cols, int* band_rows, int* tile_cols) {
     int ow = 0, bh = 0;
-    v3_geometry(&ow, &bh);
+    if (g_agg_path == 3) v3_geometry(&ow, &bh);
+    else v4_geometry(&ow, &bh);
     if (strip_cols) *strip_cols = ow;
     if (band_rows) *band_rows = bh;
     if (tile_cols) *tile_cols = ow + 2 * radius + 1;
@@ -228,20 +254,20 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
     { int rcd = check_same_device(d_workspace, "smx_dev_aggregate_wta"); if (rcd) return rcd; }
     hipStream_t st = (hipStream_t)stream;
     // fused path (smx_agg_v3.hip): radius <= 9; cost built on the fly or read from d_cost
-    const bool can_v3 = v3_supported(p);
+    const bool can_v3 = v3_supported(p) && v4_supported(p);
     if (g_agg_path == 2 && !can_v3)
         return fail(SMX_E_ARG, "smx_dev_aggregate_wta: fused path forced but radius > 9");
     if (can_v3 && g_agg_path != 1) {
         g_launches = 0;
         if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
-        int rc2 = aggregate_v3(p, 1, &d_guide, &d_other, &d_cost, w, h, &dmin, s_begin, s_end, &d_keys,
+        int rc2 = aggregate_fused(p, 1, &d_guide, &d_other, &d_cost, w, h, &dmin, s_begin, s_end, &d_keys,
                                &d_mean_u8, &d_agg, d_workspace, workspace_bytes, st, &g_launches);
         if (rc2) return rc2;
         if (g_timing) {
             SMX_HIP(hipEventRecord(g_ev1, st));
             g_ev_valid = true;
         }
-        g_last_path = 2;
+        g_last_path = g_agg_path == 3 ? 3 : 2;
         return SMX_OK;
     }
     g_last_path = 1;
@@ -329,7 +355,7 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
         float* agg[2] = {d_agg, d_agg ? d_agg + vol : nullptr};
         g_launches = 0;
         if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
-        int rc2 = aggregate_v3(p, 2, guide, other, nullptr, w, h, dmin, s_begin, s_end, keys,
+        int rc2 = aggregate_fused(p, 2, guide, other, nullptr, w, h, dmin, s_begin, s_end, keys,
                                d_mean_u8 ? mean : nullptr, d_agg ? agg : nullptr, d_workspace,
                                workspace_bytes, st, &g_launches);
         if (rc2) return rc2;
@@ -337,7 +363,7 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
             SMX_HIP(hipEventRecord(g_ev1, st));
             g_ev_valid = true;
         }
-        g_last_path = 2;
+        g_last_path = g_agg_path == 3 ? 3 : 2;
         return SMX_OK;
     }
     if (g_agg_path == 2)
@@ -543,10 +569,10 @@ int smx_stereo_pair(const smx_params* p, const uint8_t* gray_l, const uint8_t* g
         uint8_t* mv[2] = {mean.as<uint8_t>(), mean.as<uint8_t>() + n};
         float* av[2] = {aggLR.as<float>(), want_agg ? aggLR.as<float>() + (size_t)size_d * n : nullptr};
         g_launches = 0;
-        if ((rc = aggregate_v3(p, 2, guide, other, want_cost ? cost : nullptr, w, h, dmin, 0, size_d, kv, mv,
+        if ((rc = aggregate_fused(p, 2, guide, other, want_cost ? cost : nullptr, w, h, dmin, 0, size_d, kv, mv,
                                want_agg ? av : nullptr, ws.p, ws_bytes, nullptr, &g_launches)))
             return rc;
-        g_last_path = 2;
+        g_last_path = g_agg_path == 3 ? 3 : 2;
     } else {
         if ((rc = smx_dev_aggregate_wta(p, dL.as<uint8_t>(), dR.as<uint8_t>(),
                                         want_cost ? costL.as<float>() : nullptr, w, h, dminl, 0, size_d, keysL,
