@@ -64,13 +64,13 @@ typedef _Float16 fg_t __attribute__((ext_vector_type(2)));   // (pixel value, x-
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 struct View {
-    const fg_t* FG1;      // this view's image plane [h][w+2], sentinel columns at x = -1 and x = w
+    const fg_t* FG1;      // this view's image plane [h][w + 2 PADX], sentinel columns on either side
     const fg_t* FG2;      // the other view's (SRC_IMG)
     const float* cost;    // SRC_COST: [slice][h][w]
-    const float* mean;    // mean_I [h][w]
-    const float* cinv;    // 1/(var_I + eps) [h][w]
+    const f2* guid;       // (mean_I, 1/(var_I + eps)) [h][w]
     float* q;             // out: [slice][h][w]
     int d0;               // disparity of local slice 0
 };
@@ -159,9 +159,10 @@ __device__ __forceinline__ void wg_barrier() {
 }
 
 // ---------------------------------------------------------------------------------------------
-// prep: u8 image [h][w] -> (value, x-derivative) half2 plane [h][w+2] with sentinel columns.
-// grid (ceil((w+2)/256), h, nimages)            (x_derivativeOnGPU costVolume.cu:358-381)
+// prep: u8 image [h][w] -> (value, x-derivative) half2 plane [h][w + 2 PADX] with PADX sentinel columns on
+// either side.  grid (ceil((w + 2 PADX)/256), h, nimages)      (x_derivativeOnGPU costVolume.cu:358-381)
 // ---------------------------------------------------------------------------------------------
+constexpr int PADX = 4;                 // the aggregation loads four columns per lane: a quad may straddle a border
 struct PrepArgs {
     const uint8_t* I[2];
     fg_t* FG[2];
@@ -172,8 +173,8 @@ __global__ void k_v4_prep(PrepArgs pa, int w, int h) {
     fg_t* __restrict__ FG = pa.FG[blockIdx.z];
     const int xp = blockIdx.x * blockDim.x + threadIdx.x;   // padded column
     const int y = blockIdx.y;
-    if (xp >= w + 2) return;
-    const int x = xp - 1;
+    if (xp >= w + 2 * PADX) return;
+    const int x = xp - PADX;
     float f = 60000.0f, g = 60000.0f;
     if (x >= 0 && x < w) {
         const uint8_t* row = I + (size_t)y * w;
@@ -187,7 +188,130 @@ __global__ void k_v4_prep(PrepArgs pa, int w, int h) {
     fg_t v;
     v.x = (_Float16)f;
     v.y = (_Float16)g;
-    FG[(size_t)y * (w + 2) + xp] = v;
+    FG[(size_t)y * (w + 2 * PADX) + xp] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// guidance statistics (guidedFilter.cu:58-123): integral images of I and I*I (integral.cu:78-131, the
+// reference's sequential row prefix then sequential column prefix), box means, variance, 1/(var + eps).
+// Three small latency-bound kernels; the planes live in the workspace.
+// ---------------------------------------------------------------------------------------------
+struct GuidArgs {
+    const fg_t* FG[2];      // image planes of k_v4_prep
+    float* S[2][2];         // [view][plane]: integral of I, integral of I*I (scratch)
+    f2* G[2];               // out: (mean_I, 1/(var_I + eps))
+    uint8_t* mean_u8[2];    // out, optional: mean_I as u8 (flToChOnGPU guidedFilter.cu:451-458)
+};
+
+// Row prefix sums (rowSum integral.cu:78-90).  One wave per 16 rows of one view; lanes 0..31 = (row, plane).
+// The 16 x 64 tiles are loaded and stored with LANE = COLUMN (coalesced) and turned through LDS.
+constexpr int GR_ROWS = 16;
+__global__ __launch_bounds__(64) void k_v4_guid_rows(GuidArgs ga, int w, int h) {
+    __shared__ float tile[2][GR_ROWS][65];
+    const int lane = threadIdx.x, view = blockIdx.y, y0 = blockIdx.x * GR_ROWS;
+    const fg_t* __restrict__ FG = ga.FG[view];
+    float* __restrict__ S0 = ga.S[view][0];
+    float* __restrict__ S1 = ga.S[view][1];
+    const int wp = w + 2 * PADX;
+    const int srow = lane & 15, spl = (lane >> 4) & 1;
+    float acc = -0.0f;                                   // exact additive identity
+    float v[GR_ROWS];
+    auto load = [&](int x0) {
+#pragma unroll
+        for (int r = 0; r < GR_ROWS; ++r) {
+            const int y = min(y0 + r, h - 1), x = min(x0 + lane, w - 1);
+            v[r] = (float)FG[(size_t)y * wp + PADX + x].x;      // chToFlOnGPU guidedFilter.cu:442-449
+        }
+    };
+    load(0);
+    for (int x0 = 0; x0 < w; x0 += 64) {
+#pragma unroll
+        for (int r = 0; r < GR_ROWS; ++r) {
+            tile[0][r][lane] = v[r];
+            tile[1][r][lane] = v[r] * v[r];              // pixelMultOnGPU(d_im, d_im) :111
+        }
+        if (x0 + 64 < w) load(x0 + 64);                  // in flight under the scan
+        __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the tile is in LDS (one wave: no barrier)
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 32) {
+            const int nc = min(64, w - x0);
+            float* row = &tile[spl][srow][0];
+            for (int c = 0; c < nc; ++c) {
+                acc = row[c] + acc;
+                row[c] = acc;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        if (x0 + lane < w) {
+#pragma unroll
+            for (int r = 0; r < GR_ROWS; ++r) {
+                if (y0 + r < h) {
+                    S0[(size_t)(y0 + r) * w + x0 + lane] = tile[0][r][lane];
+                    S1[(size_t)(y0 + r) * w + x0 + lane] = tile[1][r][lane];
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Column prefix sums in place (colSum integral.cu:121-131).  One lane per column of one plane; 32 rows of
+// loads in flight.  grid (ceil(w/64), 2 planes, nviews)
+__global__ __launch_bounds__(64) void k_v4_guid_cols(GuidArgs ga, int w, int h) {
+    const int x = blockIdx.x * 64 + threadIdx.x;
+    if (x >= w) return;
+    float* __restrict__ p = ga.S[blockIdx.z][blockIdx.y] + x;
+    float acc = -0.0f;
+    constexpr int NB = 32;
+    float v[NB];
+    int y = 0;
+    for (; y + NB <= h; y += NB) {
+#pragma unroll
+        for (int t = 0; t < NB; ++t) v[t] = p[(size_t)(y + t) * w];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            acc = v[t] + acc;
+            p[(size_t)(y + t) * w] = acc;
+        }
+    }
+    for (; y < h; ++y) {
+        acc = p[(size_t)y * w] + acc;
+        p[(size_t)y * w] = acc;
+    }
+}
+
+// mean_I = box(S_I); var = box(S_II) - mean_I*mean_I; 1/(var + eps) in double as the reference's
+// compute_ak_and_bk (guidedFilter.cu:350).  grid (ceil(w/256), h, nviews)
+__global__ void k_v4_guid_finish(GuidArgs ga, int w, int h, int R, double eps) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, view = blockIdx.z;
+    if (x >= w) return;
+    const float* __restrict__ S0 = ga.S[view][0];
+    const float* __restrict__ S1 = ga.S[view][1];
+    const int ymin = max(-1, y - R - 1), ymax = min(h - 1, y + R);
+    const int xmin = max(-1, x - R - 1), xmax = min(w - 1, x + R);
+    const bool hx = xmin >= 0, hy = ymin >= 0;
+    const size_t i11 = (size_t)ymax * w + xmax, i10 = (size_t)ymax * w + (hx ? xmin : 0);
+    const size_t i01 = (size_t)(hy ? ymin : 0) * w + xmax, i00 = (size_t)(hy ? ymin : 0) * w + (hx ? xmin : 0);
+    const float area = (float)((xmax - xmin) * (ymax - ymin));
+    auto box = [&](const float* __restrict__ S) {      // computeBoxFilterOnGPU guidedFilter.cu:305-318
+        float val = S[i11];
+        if (hx) val -= S[i10];
+        if (hy) val -= S[i01];
+        if (hx && hy) val += S[i00];
+        return 1.0f * val / area;
+    };
+    const float m = box(S0), s = box(S1);
+    const float m2 = m * m;                             // pixelMultOnGPU(mean, mean) :112
+    const float var = s - m2;                           // pixelSousOnGPU :121
+    const float c = (float)(1.0f / ((double)var + eps));
+    const size_t id = (size_t)y * w + x;
+    ga.G[view][id] = (f2){m, c};
+    if (ga.mean_u8[view]) {
+        const int ci = (int)m;
+        ga.mean_u8[view][id] = (ci > 255) ? 255 : (uint8_t)ci;
+    }
 }
 
 // Hand-off record of one iteration (per parity and slice-view), written and read in 16-byte units:
@@ -199,18 +323,42 @@ constexpr int REC_F2 = 2 * BH + BH * HP;          // float2 per record
 constexpr int REC_U = REC_F2 / 2;                 // 16-byte units per record: one per thread
 static_assert(REC_U <= NT && HP % 2 == 0 && BH % 2 == 0, "one 16-byte hand-off unit per thread");
 
+// stage-1 input quads: four ring columns of one row per lane (one 16-byte load per image), held by waves 2..7
+constexpr int NQ = (TWMAX + 3) / 4;               // quads per ring row (21; the last one ends in the pitch padding)
+constexpr int QW0 = 2;                            // first wave that holds quads
+constexpr int QTH = NT - 64 * QW0;                // threads that hold quads
+static_assert(NQ * 4 <= PITCH && NQ <= 4 * (NWAVE - QW0) && BH == 32, "two quads (rows r, r + 16) per quad-holding thread");
+
 // Diagnostic build only (-DSMX_V4_STAMPS=<item>): every wave of one work item records the shader clock
 // at its phase boundaries; the product build contains no stamp.
 #ifdef SMX_V4_STAMPS
-constexpr int STAMP_SLOTS = 5 * 64;
+constexpr int STAMP_W = 12;             // stamps per iteration
+constexpr int STAMP_SLOTS = STAMP_W * 40;
 __device__ unsigned long long g_stamps[NWAVE * STAMP_SLOTS];
-#define V4_STAMP(n)                                                                       \
-    do {                                                                                  \
-        if (item == SMX_V4_STAMPS && lane == 0 && i * 5 + (n) < STAMP_SLOTS)               \
-            g_stamps[wave * STAMP_SLOTS + i * 5 + (n)] = __builtin_amdgcn_s_memtime();     \
+#define V4_STAMP(n)                                                                          \
+    do {                                                                                     \
+        if (item == SMX_V4_STAMPS && lane == 0 && i * STAMP_W + (n) < STAMP_SLOTS)            \
+            g_stamps[wave * STAMP_SLOTS + i * STAMP_W + (n)] = __builtin_amdgcn_s_memtime();  \
     } while (0)
 #else
 #define V4_STAMP(n) ((void)0)
+#endif
+// Diagnostic build only (-DSMX_V4_DUMP=<item> -DSMX_V4_DUMP_IT=<iteration> -DSMX_V4_DUMP_PH=<0..3: behind the
+// barrier that ends W / R / C / X>): both LDS rings of one work item at one point -> global memory
+#ifdef SMX_V4_DUMP
+__device__ float g_dump[2 * 2 * RR * PITCH];
+#define V4_DUMP(ph)                                                                               \
+    do {                                                                                          \
+        if (item == SMX_V4_DUMP && i == SMX_V4_DUMP_IT && (ph) == SMX_V4_DUMP_PH) {                \
+            for (int e_ = tid; e_ < 2 * RR * PITCH; e_ += NT) {                                    \
+                g_dump[e_] = ((const float*)ring1)[e_];                                            \
+                g_dump[2 * RR * PITCH + e_] = ((const float*)ring2)[e_];                           \
+            }                                                                                     \
+            wg_barrier();                                                                         \
+        }                                                                                         \
+    } while (0)
+#else
+#define V4_DUMP(ph) ((void)0)
 #endif
 #ifdef SMX_V4_ITEMLOG
 constexpr int ITEMLOG_MAX = 1 << 16;
@@ -219,12 +367,21 @@ __device__ unsigned long long g_itemlog[3 * ITEMLOG_MAX];
 
 constexpr unsigned FLAG_DONE = 0x7fffffffu;
 
+// A value the compiler must re-derive where it is used: per-lane constants of the whole item (lane geometry,
+// unit indices) are recomputed from the lane index in a few VALU instructions instead of living in VGPRs
+// across all four phases of every iteration.
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+typedef __attribute__((address_space(3))) const char lds_cc;
+__device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(lds_cc*)p; }
+// one ds_read_b64 the compiler cannot pair into a ds_read2_b64 (which takes four times the LDS cycles of two
+// ds_read_b64 for the same bytes); the caller waits with lds_wait16() before the first use
+#define LDS_RD64(dst, addr, imm) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+
 // RT: compile-time box radius (RMAX) or -1 = the radius of the call (A.R <= RMAX)
 template <int SRC, int RT>
 __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
     __shared__ __attribute__((aligned(16))) f2 ring1[RR * PITCH];   // stage-1 row y at ring row y mod RR
     __shared__ __attribute__((aligned(16))) f2 ring2[RR * PITCH];   // a/b row y at ring row (y + R) mod RR
-    __shared__ __attribute__((aligned(16))) f2 cin[2][BH];          // row carries in : stage -> rows of the band
     __shared__ __attribute__((aligned(16))) f2 cout[2][BH];         // row carries out
     __shared__ float rcp_s[HWMAX * HWMAX + 1];                      // RN(1/area)
     __shared__ int s_item, s_next;
@@ -239,18 +396,41 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
     const f2 ident = {-0.0f, -0.0f};            // exact additive identity: v + (-0) == v
     if (tid <= HWMAX * HWMAX) rcp_s[tid] = kRcp.v[tid];
 
-    // this thread's 16-byte unit of a hand-off record
-    const bool hu_on = tid < REC_U;
-    int hu_r = 0, hu_c = 0;                     // halo units: row of the band, first of the two columns
-    if (tid >= BH) {
-        const int u = tid - BH;
-        hu_r = u / (HP / 2);
-        hu_c = (u - hu_r * (HP / 2)) * 2;
-    }
+    // Hand-off units.  In: the row-scan lanes (waves 0, 1) load their own carry dword; the threads of waves
+    // QW0.. load one 16-byte halo unit each (two columns of one row).  Out: the same threads store the halo
+    // units, the next BH of them the row carries of both stages (two rows per unit).
+    const int qt = tid - 64 * QW0;              // index among the threads of waves QW0..
+    constexpr int NHALO_U = BH * HP / 2;        // halo units per record
+    static_assert(NHALO_U + BH <= QTH, "one hand-off unit per thread of waves QW0..");
+    const bool hu_halo = qt >= 0 && qt < NHALO_U;
+    const bool hu_carry = qt >= NHALO_U && qt < NHALO_U + BH;
+    // halo unit: row of the band, first of the two columns; byte offset of the unit inside a record
+    auto hu_rc = [&](int& r, int& c) {
+        const int u = max(opaque(qt), 0);
+        r = u / (HP / 2);
+        c = (u - r * (HP / 2)) * 2;
+    };
+    auto hu_off = [&]() {
+        const int u = opaque(qt);
+        return u < NHALO_U ? (unsigned)(2 * BH * 8 + u * 16) : (unsigned)((u - NHALO_U) * 16);
+    };
     // row-scan lanes: each 32-lane group (the unit of LDS banking for dword accesses) takes half of the rows
     // with both components, lanes 0-15 / 16-31 = first / second component: 16 distinct even + 16 distinct
     // odd banks (row stride 170 dwords = 10 mod 32)
-    const int srow = (lane & 15) + 16 * (lane >> 5), scomp = (lane >> 4) & 1;
+    auto srow_of = [&]() { const int l = opaque(lane); return (l & 15) + 16 * (l >> 5); };
+    auto scomp_of = [&]() { return (opaque(lane) >> 4) & 1; };
+    // this thread's two stage-1 input quads (waves QW0..): row of the band, first ring column
+    // One wave-instruction covers 16 rows x 4 quads: the LDS writes of a 16-lane group then go to 16 different
+    // rows (row stride 170 dwords = 10 mod 32: conflict-free), the global loads to 64-byte runs of 16 rows.
+    // Wave QW0 + g takes the quads 4g .. 4g+3 of a row; its two rounds the rows 0..15 / 16..31 of the band.
+    bool q_on[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) q_on[e] = wave >= QW0 && 4 * (wave - QW0) + (lane >> 4) < NQ;
+    auto quad_rc = [&](int e, int& r, int& c) {
+        const int l = opaque(lane);
+        r = 16 * e + (l & 15);
+        c = (4 * (wave - QW0) + (l >> 4)) * 4;
+    };
 
     if (tid == 0) s_item = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
@@ -283,107 +463,130 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
         // whose column lies outside the image carries the offset OOB, which is beyond every plane: its loads
         // return 0 and its stores are dropped by the range check.
         constexpr unsigned OOB = 0x80000000u;
-        const unsigned fgw4 = ((unsigned)w + 2u) * 4u, w4 = (unsigned)w * 4u;
-        const unsigned pitch2 = SRC == SRC_IMG ? fgw4 : w4;      // row pitch of the second stage-1 input
+        const unsigned fgw4 = ((unsigned)w + 2u * PADX) * 4u, w4 = (unsigned)w * 4u;
         const size_t plane = (size_t)h * w;
         const rsrc_t r_fg1 = mk_rsrc(V.FG1, (size_t)h * fgw4);
         const rsrc_t r_in2 = SRC == SRC_IMG ? mk_rsrc(V.FG2, (size_t)h * fgw4)
                                             : mk_rsrc(V.cost + (size_t)slice * plane, plane * 4);
-        const rsrc_t r_ga = mk_rsrc(V.mean, plane * 4);
-        const rsrc_t r_gb = mk_rsrc(V.cinv, plane * 4);
+        const rsrc_t r_g = mk_rsrc(V.guid, plane * 8);
         const rsrc_t r_q = mk_rsrc(V.q + (size_t)slice * plane, plane * 4);
 
-        // per-lane window geometry in x: fixed for the whole item
+        // per-lane window geometry in x (needed by the clipped box only) and the byte offset (x4) of a lane's
+        // column in a row
         struct Geo { int jmax, jmin, xcw; bool hx; };
-        unsigned vq, vg;                     // byte offset of this lane's q column / a_k, b_k column in a row
-        Geo g1, g2;
-        {
-            auto mkgeo = [&](int x, int cs, unsigned& off4) {
-                Geo g;
-                const bool xin = x >= 0 && x < w;
-                const int xc = min(max(x, 0), w - 1);
-                const int xmax = min(w - 1, xc + R), xmn = xc - R - 1;
-                g.hx = xmn >= 0;
-                g.xcw = xmax - (g.hx ? xmn : -1);
-                g.jmax = min(max(xmax - cs, 0), TW - 1);
-                g.jmin = min(max(xmn - cs, 0), TW - 1);
-                off4 = xin ? (unsigned)xc * 4u : OOB;
-                return g;
-            };
-            g1 = mkgeo(xs + lane, cs1, vg);
-            g2 = mkgeo(xs - R + lane, cs2, vq);
-        }
+        auto mkgeo = [&](int x, int cs) {
+            Geo g;
+            const int xc = min(max(x, 0), w - 1);
+            const int xmax = min(w - 1, xc + R), xmn = xc - R - 1;
+            g.hx = xmn >= 0;
+            g.xcw = xmax - (g.hx ? xmn : -1);
+            g.jmax = min(max(xmax - cs, 0), TW - 1);
+            g.jmin = min(max(xmn - cs, 0), TW - 1);
+            return g;
+        };
+        auto coloff = [&](int x) { return x >= 0 && x < w ? (unsigned)x * 4u : OOB; };
+        auto vg_of = [&]() { return coloff(xs + opaque(lane)); };        // a_k, b_k column
+        auto vq_of = [&]() { return coloff(xs - R + opaque(lane)); };    // q column
         // all 64 windows of the strip unclipped in x: no selects, one area
         const bool xint1 = xs - R - 1 >= 0 && xs + OW - 1 + R <= w - 1;
         const bool xint2 = xs - 2 * R - 1 >= 0 && xs + OW - 1 <= w - 1;
         const float area_full = (float)(HW * HW), ra_full = rcp_s[HW * HW];
 
-        // stage-1 input cells of this lane, fixed for the item: rows 4 wave + t at ring column `lane` (cells
-        // 0..3) and rows 4 wave + 2e + (lane >> 5) at ring column 64 + (lane & 31) (cells 4, 5).  Columns are
-        // clamped into the image instead of predicated: cells outside it are written but never accumulated.
-        const int rsel = lane >> 5;
-        const bool e2_ok = (lane & 31) < HW;
-        unsigned in1a, in1b, in2a, in2b;     // byte offsets inside a row: cells 0..3 and cells 4, 5; first / second input
-        {
-            auto cell = [&](int j, unsigned& o1, unsigned& o2) {
-                const int c = min(max(cs1 + j, 0), w - 1);
-                o1 = (unsigned)(c + 1) * 4u;
-                if (SRC == SRC_IMG) {
-                    int xx = c + d;
-                    xx = xx < -1 ? -1 : (xx > w ? w : xx);   // sentinel columns
-                    o2 = (unsigned)(xx + 1) * 4u;
-                } else {
-                    o2 = (unsigned)c * 4u;
-                }
-            };
-            cell(lane, in1a, in2a);
-            cell(64 + (lane & 31), in1b, in2b);
-        }
         const int jlo1 = max(0, -cs1), jhi1 = min(TW, w - cs1);   // ring-1 columns inside the image
         const int jlo2 = HW, jhi2 = min(TW, w - cs2);             // new ring-2 columns inside the image
 
-        uint32_t ua[6], ub[6];               // raw stage-1 inputs of the next band
-        float ga[RPW], gb[RPW];              // mean_I, 1/(var+eps) of the a/b rows of the next X phase
+        // stage-1 inputs of the next band: raw quads (four (value, gradient) cells of this view / of the other view,
+        // or four raw costs), loaded in W(i); evaluated to (p, I p) under the row scans of R(i); written in W(i+1)
+        u4 qa[2], qb[2];
+        f2 qres[2][4];
+        f2 gab[RPW];                         // (mean_I, 1/(var+eps)) of the a/b rows of the next X phase
         uint32_t Iraw[RPW];                  // raw (value, gradient) halves of the q rows of the next X phase
         f2 abreg[RPW];                       // a_k, b_k of this wave's rows, written to ring 2 in the next W phase
-        f4 hreg = {0, 0, 0, 0};              // this thread's unit of the left neighbour's next record
+        f4 hreg = {0, 0, 0, 0};              // this thread's halo unit of the left neighbour's next record (waves QW0..)
+        float creg = -0.0f;                  // this row-scan lane's carry of the left neighbour's next record (waves 0, 1)
         bool have_pref = false;
         unsigned seen = 0;
 #pragma unroll
         for (int t = 0; t < RPW; ++t) { abreg[t] = ident; }
 
-        // loads for iteration ib: stage-1 inputs of band ib, guidance of its a/b rows, guidance image of its q
-        // rows.  Rows are clamped into the image: every load is issued whether its row exists or not.
-        auto issue_next = [&](int ib) {
-            const int y0 = BH * ib + RPW * wave;
-#pragma unroll
-            for (int t = 0; t < RPW; ++t) {
-                const int ye = min(y0 + t, h - 1);
-                ua[t] = ldu(r_fg1, in1a, ye * (int)fgw4);
-                ub[t] = ldu(r_in2, in2a, ye * (int)pitch2);
-            }
+        // loads of the stage-1 inputs of band ib (rows clamped into the image: every load is issued)
+        auto issue_cost = [&](int ib) {
+            if (wave < QW0) return;
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int ye0 = min(y0 + 2 * e, h - 1), ye1 = min(y0 + 2 * e + 1, h - 1);
-                const unsigned dy = (unsigned)(ye1 - ye0);   // 1, or 0 on the last image row
-                ua[4 + e] = ldu(r_fg1, in1b + (rsel ? dy * fgw4 : 0u), ye0 * (int)fgw4);
-                ub[4 + e] = ldu(r_in2, in2b + (rsel ? dy * pitch2 : 0u), ye0 * (int)pitch2);
+                if (!q_on[e]) continue;
+                int qr, qc;
+                quad_rc(e, qr, qc);
+                // a quad wholly outside the image is moved onto the sentinel columns (its cells are written but
+                // never accumulated)
+                const unsigned y = (unsigned)min(BH * ib + qr, h - 1);
+                const int c1 = min(max(cs1 + qc, -PADX), w);
+                qa[e] = __builtin_amdgcn_raw_buffer_load_b128(r_fg1, (int)((unsigned)(c1 + PADX) * 4u + y * fgw4), 0, 0);
+                if (SRC == SRC_IMG) {
+                    const int c2 = min(max(cs1 + qc + d, -PADX), w);
+                    qb[e] = __builtin_amdgcn_raw_buffer_load_b128(r_in2, (int)((unsigned)(c2 + PADX) * 4u + y * fgw4), 0, 0);
+                } else {
+                    unsigned c4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = min(max(cs1 + qc + j, 0), w - 1);
+                        c4[j] = ldu(r_in2, (unsigned)c * 4u + y * w4, 0);
+                    }
+                    qb[e] = (u4){c4[0], c4[1], c4[2], c4[3]};
+                }
             }
+        };
+        // raw -> (p, I p)
+        auto eval_cost = [&]() {
+            if (wave < QW0) return;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                if (!q_on[e]) continue;
+                const unsigned ra[4] = {qa[e].x, qa[e].y, qa[e].z, qa[e].w};
+                const unsigned rb4[4] = {qb[e].x, qb[e].y, qb[e].z, qb[e].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const fg_t q1 = __builtin_bit_cast(fg_t, ra[j]);
+                    f2 v;
+                    if (SRC == SRC_IMG) {
+                        v = cost_pair(q1, __builtin_bit_cast(fg_t, rb4[j]), cc);
+                    } else {
+                        v.x = __builtin_bit_cast(float, rb4[j]);   // copyFromBigToLittleOnGPU guidedFilter.cu:198
+                        v.y = (float)q1.x * v.x;                   // pixelMultOnGPU(d_im, d_p) :209
+                    }
+                    qres[e][j] = v;
+                }
+            }
+        };
+        // loads for the X phase of iteration ib: guidance of its a/b rows, guidance image of its q rows
+        auto issue_guid = [&](int ib) {
+            const unsigned vg = vg_of(), vq = vq_of();
+            const unsigned vg8 = vg == OOB ? OOB : 2u * vg;          // this lane's a/b column in the float2 guidance plane
+            const unsigned vqI = vq == OOB ? OOB : vq + 4u * PADX;   // this lane's q column in the padded image plane
             const int ya0 = BH * ib - R + RPW * wave;
 #pragma unroll
             for (int t = 0; t < RPW; ++t) {
                 const int y = min(max(ya0 + t, 0), h - 1);
-                ga[t] = __builtin_bit_cast(float, ldu(r_ga, vg, y * (int)w4));
-                gb[t] = __builtin_bit_cast(float, ldu(r_gb, vg, y * (int)w4));
+                const u2 g = __builtin_amdgcn_raw_buffer_load_b64(r_g, (int)vg8, y * (int)(2u * w4), 0);
+                gab[t] = __builtin_bit_cast(f2, g);
             }
             const int yq0 = BH * (ib - 1) - 2 * R + RPW * wave;
 #pragma unroll
             for (int t = 0; t < RPW; ++t) {
                 const int y = min(max(yq0 + t, 0), h - 1);
-                Iraw[t] = ldu(r_fg1, vq, y * (int)fgw4 + 4);     // column + 1 in the padded plane
+                Iraw[t] = ldu(r_fg1, vqI, y * (int)fgw4);
             }
         };
 
+        // loads of this thread's part of the left neighbour's record `rec` (sc1: the hand-off form of the guide)
+        auto fetch_rec = [&](int rec) {
+            const unsigned base = (unsigned)(rec * REC_F2 * 8);
+            if (wave < QW0)
+                creg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                           r_in, (int)(base + (unsigned)((wave * BH + srow_of()) * 8 + scomp_of() * 4)), 0, AUX_SC1));
+            else if (hu_halo)
+                hreg = ld16_sc1(r_in, base + hu_off());
+        };
         // bounded wait for the left neighbour's flag >= need (thread 0 only); result -> s_seen
         auto spin_pred = [&](unsigned need) {
             const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
@@ -404,11 +607,12 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
         // ---- row scan of one band: this lane = one component of one row ------------------------------------
         auto rowscan = [&](f2* ring, int st, int rbase, int yband, int jlo, int jhi, bool full, auto NCOL) {
             constexpr int NC = decltype(NCOL)::value;      // columns of the unrolled form
+            const int srow = srow_of(), scomp = scomp_of();
             const int y = yband + srow;
             if (y < 0 || y >= h || jhi <= jlo) return;
             int rr = rbase + srow;
             rr = rr >= RR ? rr - RR : rr;
-            float acc = pred ? ((const float*)&cin[st][srow])[scomp] : -0.0f;
+            float acc = pred ? creg : -0.0f;
             float* row = (float*)(ring + rr * PITCH) + scomp;   // column c of this component: row[2 c]
             if (full) {
                 // the common case: NC columns from jlo, fully unrolled so that every LDS wait is a counted one;
@@ -477,33 +681,31 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
             else ((float*)&cout[1][srow])[scomp] = acc;
         };
 
-        // ---- column scan of one band for the ring column of this lane (LANE = COLUMN) ----------------------
+        // ---- column scan of one band for the dword `idx` (column, component) of this lane -------------------
         // rows yband + t at ring rows (rbase + t) mod RR; groups of four rows never wrap (RR % 4 == 0)
-        auto colscan = [&](f2* ring, int col, int rbase, int yband, f2& S) {
-            f2* const pc = ring + col;
+        auto colscan = [&](f2* ring, int idx, int rbase, int yband, float& S) {
+            float* const pc = (float*)ring + idx;
+            constexpr int P2 = 2 * PITCH;
             if (yband >= 0 && yband + BH <= h) {
-                // full band: the reads of the next group of four rows are issued before the adds of this one
-                f2 v[2][4];
+                // full band: all reads in flight, then the dependent chain of adds with its writes
+                float v[BH];
+                float* pg[BH / 4];
                 int rr = rbase;
-                f2* p = pc + rr * PITCH;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) v[0][t] = p[t * PITCH];
 #pragma unroll
                 for (int g = 0; g < BH / 4; ++g) {
-                    int rn = rr + 4;
-                    rn = rn >= RR ? rn - RR : rn;
-                    f2* pn = pc + rn * PITCH;
-                    if (g + 1 < BH / 4) {
+                    pg[g] = pc + rr * P2;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) v[(g + 1) & 1][t] = pn[t * PITCH];
-                    }
+                    for (int t = 0; t < 4; ++t) v[4 * g + t] = pg[g][t * P2];
+                    rr += 4;
+                    rr = rr >= RR ? rr - RR : rr;
+                }
+#pragma unroll
+                for (int g = 0; g < BH / 4; ++g) {
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        S = v[g & 1][t] + S;
-                        p[t * PITCH] = S;
+                        S = v[4 * g + t] + S;
+                        pg[g][t * P2] = S;
                     }
-                    rr = rn;
-                    p = pn;
                 }
                 return;
             }
@@ -512,8 +714,8 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
                 if (y < 0 || y >= h) continue;
                 int rr = rbase + t;
                 rr = rr >= RR ? rr - RR : rr;
-                S = pc[rr * PITCH] + S;
-                pc[rr * PITCH] = S;
+                S = pc[rr * P2] + S;
+                pc[rr * P2] = S;
             }
         };
 
@@ -521,38 +723,65 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
         // S01 + S00 in that order, then a true division by the window area) ---------------------------------
         // fast form: every window of the band is unclipped in x and y.  rbase = ring row of the band's first
         // bottom tap row (the top tap row is 2R+1 ring rows above it).
-        auto box4_fast = [&](const f2* ring, int rbase, f2 (&m)[RPW]) {
+        auto box2_fast = [&](const f2* ring, int rbase, int half, f2* m) {
             int rb0 = rbase + RPW * wave;
-            rb0 = rb0 >= RR ? rb0 - RR : rb0;
-            f2 s11[RPW], s10[RPW], s01[RPW], s00[RPW], val[RPW];
+            rb0 = rb0 >= RR ? rb0 - RR : rb0;            // the wave's group of four bottom rows never wraps
+            rb0 += 2 * half;
+            f2 s11[2], s10[2], s01[2], s00[2], val[2];
+            if (RT == RMAX) {
+                constexpr int HWB = (2 * (RT >= 0 ? RT : 0) + 1) * 8;
+                const unsigned ab = lds_off(ring + rb0 * PITCH + lane);
+                int rt0 = rb0 - HW, rt1 = rb0 + 1 - HW;
+                rt0 = rt0 < 0 ? rt0 + RR : rt0;
+                rt1 = rt1 < 0 ? rt1 + RR : rt1;
+                const unsigned at0 = lds_off(ring + rt0 * PITCH + lane), at1 = lds_off(ring + rt1 * PITCH + lane);
+                LDS_RD64(s11[0], ab, HWB);
+                LDS_RD64(s10[0], ab, 0);
+                LDS_RD64(s01[0], at0, HWB);
+                LDS_RD64(s00[0], at0, 0);
+                LDS_RD64(s11[1], ab, PITCH * 8 + HWB);
+                LDS_RD64(s10[1], ab, PITCH * 8);
+                LDS_RD64(s01[1], at1, HWB);
+                LDS_RD64(s00[1], at1, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(s11[0]), "+v"(s10[0]), "+v"(s01[0]), "+v"(s00[0]), "+v"(s11[1]), "+v"(s10[1]), "+v"(s01[1]),
+                               "+v"(s00[1]));
+            } else {
 #pragma unroll
-            for (int t = 0; t < RPW; ++t) {
-                int rt = rb0 + t - HW;
-                rt = rt < 0 ? rt + RR : rt;
-                const f2* pb = ring + (rb0 + t) * PITCH + lane;
-                const f2* pt = ring + rt * PITCH + lane;
-                s11[t] = pb[HW]; s10[t] = pb[0];
-                s01[t] = pt[HW]; s00[t] = pt[0];
+                for (int t = 0; t < 2; ++t) {
+                    int rt = rb0 + t - HW;
+                    rt = rt < 0 ? rt + RR : rt;
+                    const f2* pb = ring + (rb0 + t) * PITCH + lane;
+                    const f2* pt = ring + rt * PITCH + lane;
+                    s11[t] = pb[HW]; s10[t] = pb[0];
+                    s01[t] = pt[HW]; s00[t] = pt[0];
+                }
             }
-            bool slow = false;
+            float amin = __builtin_inff(), amax = 0.0f;
 #pragma unroll
-            for (int t = 0; t < RPW; ++t) {
+            for (int t = 0; t < 2; ++t) {
                 f2 v = s11[t] - s10[t];
                 v = v - s01[t];
                 v = v + s00[t];
                 val[t] = v;
                 m[t].x = div_small_int(v.x, area_full, ra_full);
                 m[t].y = div_small_int(v.y, area_full, ra_full);
-                slow = slow || div_needs_exact(v.x) || div_needs_exact(v.y);
+                amin = fminf(amin, fminf(fabsf(v.x), fabsf(v.y)));
+                amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
             }
-            if (__any(slow)) {
+            // tiny, zero, infinite window sums (a NaN sum gives a NaN mean on either path)
+            if (__any(!(amin >= 0x1p-100f) || !(amax < __builtin_inff()))) {
                 asm volatile("; exact-division slow path");   // keep this a real (rare) wave-uniform branch
 #pragma unroll
-                for (int t = 0; t < RPW; ++t) {
+                for (int t = 0; t < 2; ++t) {
                     m[t].x = 1.0f * val[t].x / area_full;
                     m[t].y = 1.0f * val[t].y / area_full;
                 }
             }
+        };
+        auto box4_fast = [&](const f2* ring, int rbase, f2 (&m)[RPW]) {
+            box2_fast(ring, rbase, 0, &m[0]);
+            box2_fast(ring, rbase, 1, &m[2]);
         };
         // general form: windows clipped at the image borders; rows y0 + t that do not exist are skipped
         // (ok[t] = false).  shift = 0 (ring 1) or R (ring 2).
@@ -592,36 +821,36 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
         };
 
         // ===================================== the band loop ==============================================
-        // prologue: loads of iteration 0; the left neighbour's record 0
-        issue_next(0);
+        // prologue: stage-1 inputs of band 0 (evaluated here; band i+1 is loaded in W(i) and evaluated under the
+        // row scans of R(i)), the loads of X(0), the left neighbour's record 0
+        issue_cost(0);
+        issue_guid(0);
         if (pred) {
             if (tid == 0) spin_pred(1u);
             wg_barrier();
             seen = s_seen;
-            if (hu_on) hreg = ld16_sc1(r_in, (unsigned)(tid * 16));
+            fetch_rec(0);
             have_pref = true;
         }
-        f2 S1 = ident, S2 = ident;          // running column sums of this lane's column (waves 0, 1 / wave 2)
+        eval_cost();
+        float Sc = -0.0f;                   // running column sum of this lane's dword (waves 0..4)
         int rb = 0, rbp = 0;                // ring row of the first row of band i / band i-1 (both rings)
         for (int i = 0; i < NI; ++i) {
             // ------------------------------------ W(i) --------------------------------------------------
             V4_STAMP(0);
             {
-                int rw = rb + RPW * wave;
-                rw = rw >= RR ? rw - RR : rw;
-                f2* const rb1 = ring1 + rw * PITCH;
+                if (wave >= QW0) {
 #pragma unroll
-                for (int e = 0; e < 6; ++e) {
-                    const fg_t q1 = __builtin_bit_cast(fg_t, ua[e]);
-                    f2 v;
-                    if (SRC == SRC_IMG) {
-                        v = cost_pair(q1, __builtin_bit_cast(fg_t, ub[e]), cc);
-                    } else {
-                        v.x = __builtin_bit_cast(float, ub[e]);   // copyFromBigToLittleOnGPU guidedFilter.cu:198
-                        v.y = (float)q1.x * v.x;                  // pixelMultOnGPU(d_im, d_p) :209
+                    for (int e = 0; e < 2; ++e) {
+                        if (!q_on[e]) continue;
+                        int qr, qc;
+                        quad_rc(e, qr, qc);
+                        int rw = rb + qr;
+                        rw = rw >= RR ? rw - RR : rw;
+                        f2* dst = ring1 + rw * PITCH + qc;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) dst[j] = qres[e][j];
                     }
-                    if (e < 4) rb1[e * PITCH + lane] = v;
-                    else if (e2_ok) rb1[(2 * (e - 4) + rsel) * PITCH + 64 + (lane & 31)] = v;
                 }
                 if (i >= 1) {
                     int rw2 = rbp + RPW * wave;
@@ -629,77 +858,83 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
 #pragma unroll
                     for (int t = 0; t < RPW; ++t) ring2[(rw2 + t) * PITCH + HW + lane] = abreg[t];
                 }
-                if (pred) {
-                    if (!have_pref) {
-                        // the neighbour had not published record i when this item looked: wait for it now
-                        if (tid == 0) spin_pred((unsigned)i + 1u);
-                        wg_barrier();
-                        seen = s_seen;
-                        if (hu_on) hreg = ld16_sc1(r_in, (unsigned)((i * REC_F2) * 8 + tid * 16));
-                    }
-                    if (hu_on) {
-                        if (tid < BH / 2) *(f4*)&cin[0][2 * tid] = hreg;
-                        else if (tid < BH) *(f4*)&cin[1][2 * (tid - BH / 2)] = hreg;
-                        else if (i >= 1 && hu_c < HW) {
-                            int rr = rbp + hu_r;
-                            rr = rr >= RR ? rr - RR : rr;
-                            f2* dst = ring2 + rr * PITCH + hu_c;
-                            dst[0] = (f2){hreg.x, hreg.y};
-                            if (hu_c + 1 < HW) dst[1] = (f2){hreg.z, hreg.w};
-                        }
-                    }
-                    have_pref = false;
+                if (pred && !have_pref) {
+                    // the neighbour had not published record i when this item looked: wait for it now
+                    if (tid == 0) spin_pred((unsigned)i + 1u);
+                    wg_barrier();
+                    seen = s_seen;
+                    fetch_rec(i);
                 }
+                have_pref = false;
             }
-            // every wave drains its global accesses here: the record stored in X(i-1) is complete in memory
-            // before the barrier behind which one lane publishes it
-            drain_vmem();
-            wg_barrier();
+            if (i + 1 < NI) issue_cost(i + 1);      // lands under the row scans
             V4_STAMP(1);
+            wg_barrier();
+            V4_STAMP(2);
+            V4_DUMP(0);
             // ------------------------------------ R(i) --------------------------------------------------
+            // the scans are dependent chains on the critical path of the iteration: let them win the issue
+            // arbitration against the waves (of this and the other workgroup) that share their SIMDs
             if (wave == 0) {
-                if (succ && lane == 0 && i >= 1) flag_store(myflag, (unsigned)i);
+                __builtin_amdgcn_s_setprio(3);
                 rowscan(ring1, 0, rb, BH * i, jlo1, jhi1, RT == RMAX && jlo1 == 0 && jhi1 == TWMAX,
                         std::integral_constant<int, TWMAX>{});
+                __builtin_amdgcn_s_setprio(0);
             } else if (wave == 1) {
+                __builtin_amdgcn_s_setprio(3);
                 if (i >= 1)
                     rowscan(ring2, 1, rbp, BH * (i - 1) - R, jlo2, jhi2, RT == RMAX && jhi2 == TWMAX,
                             std::integral_constant<int, OW>{});
-            } else if (wave == NWAVE - 1 && lane == 0) {
-                // an otherwise idle lane looks at the left neighbour's flag for the prefetch of record i+1
-                if (pred && seen != FLAG_DONE && seen < (unsigned)i + 2u) s_seen = flag_load(myflag - 1);
-                // ticket of the next item, one iteration before the end
-                if (i == NI - 1)
-                    s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            wg_barrier();
-            V4_STAMP(2);
-            // ------------------------------------ C(i) --------------------------------------------------
-            if (wave == 0) {
-                colscan(ring1, lane, rb, BH * i, S1);
-            } else if (wave == 1) {
-                if (lane < HW) colscan(ring1, OW + lane, rb, BH * i, S1);
-            } else if (wave == 2) {
-                if (i >= 1) colscan(ring2, HW + lane, rbp, BH * (i - 1) - R, S2);
-            }
-            wg_barrier();
-            V4_STAMP(3);
-            // ------------------------------------ X(i) --------------------------------------------------
-            seen = s_seen;
-            if (succ && hu_on) {
-                // record i: row carries of this iteration's row scans, last 2R+1 columns of the stage-2 integral
-                f4 v;
-                if (tid < BH / 2) v = *(const f4*)&cout[0][2 * tid];
-                else if (tid < BH) v = *(const f4*)&cout[1][2 * (tid - BH / 2)];
-                else {
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+                if (wave == NWAVE - 1 && lane == 0) {
+                    // an otherwise idle lane looks at the left neighbour's flag for the prefetch of record i+1
+                    if (pred && seen != FLAG_DONE && seen < (unsigned)i + 2u) s_seen = flag_load(myflag - 1);
+                    // ticket of the next item, one iteration before the end
+                    if (i == NI - 1)
+                        s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (i + 1 < NI) eval_cost();
+                // the left neighbour's last 2R+1 columns of the stage-2 integral of band i-1 -> ring 2 (nobody
+                // touches these columns before X(i))
+                int hu_r, hu_c;
+                hu_rc(hu_r, hu_c);
+                if (pred && hu_halo && i >= 1 && hu_c < HW) {
                     int rr = rbp + hu_r;
                     rr = rr >= RR ? rr - RR : rr;
-                    const f2* p = ring2 + rr * PITCH + OW + hu_c;
-                    const f2 a = p[0], b = p[1];
-                    v = (f4){a.x, a.y, b.x, b.y};
+                    f2* dst = ring2 + rr * PITCH + hu_c;
+                    dst[0] = (f2){hreg.x, hreg.y};
+                    if (hu_c + 1 < HW) dst[1] = (f2){hreg.z, hreg.w};
                 }
-                st16_sc1(r_out, (unsigned)((i * REC_F2) * 8 + tid * 16), v);
+                // every storing wave drains its global accesses here: the record stored in X(i-1) is complete in
+                // memory before the barrier behind which one lane publishes it
+                drain_vmem();
             }
+            V4_STAMP(3);
+            wg_barrier();
+            V4_STAMP(4);
+            V4_DUMP(1);
+            // ------------------------------------ C(i) --------------------------------------------------
+            if (succ && tid == NT - 1 && i >= 1) flag_store(myflag, (unsigned)i);
+            // one dword (column, component) of a ring row per lane, lane-linear along the row
+            if (wave < 3) {
+                __builtin_amdgcn_s_setprio(3);
+                const int cidx1 = 64 * wave + opaque(lane);                      // stage 1: dwords [0, 2 TW)
+                if (cidx1 < 2 * TW) colscan(ring1, cidx1, rb, BH * i, Sc);
+                __builtin_amdgcn_s_setprio(0);
+            } else if (wave < 5) {
+                __builtin_amdgcn_s_setprio(3);
+                const int cidx2 = 2 * HW + 64 * (wave - 3) + opaque(lane);       // stage 2: dwords [2 HW, 2 TW)
+                if (i >= 1) colscan(ring2, cidx2, rbp, BH * (i - 1) - R, Sc);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            V4_STAMP(5);
+            wg_barrier();
+            V4_STAMP(6);
+            V4_DUMP(2);
+            // ------------------------------------ X(i) --------------------------------------------------
+            seen = s_seen;
+            V4_STAMP(8);
             if (i >= 1) {
                 // box means of stage 2 -> q rows [BH (i-1) - 2R, BH i - 2R)
                 const int yq0 = BH * (i - 1) - 2 * R + RPW * wave;
@@ -710,8 +945,9 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
 #pragma unroll
                     for (int t = 0; t < RPW; ++t) ok[t] = true;
                 } else {
-                    box4_gen(ring2, R, g2, xint2, yq0, m, ok);
+                    box4_gen(ring2, R, mkgeo(xs - R + opaque(lane), cs2), xint2, yq0, m, ok);
                 }
+                const unsigned vq = vq_of();
 #pragma unroll
                 for (int t = 0; t < RPW; ++t) {
                     const float Iv = (float)__builtin_bit_cast(fg_t, Iraw[t]).x;
@@ -720,6 +956,7 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
                                                           min(max(yq0 + t, 0), h - 1) * (int)w4, AUX_NT);
                 }
             }
+            V4_STAMP(9);
             {
                 // box means of stage 1 -> a_k, b_k rows [BH i - R, BH i + BH - R)   (compute_ak_and_bk guidedFilter.cu:345-354)
                 const int ya0 = BH * i - R + RPW * wave;
@@ -728,26 +965,43 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
                 if (xint1 && BH * i - 2 * R - 1 >= 0 && BH * i + BH <= h) {
                     box4_fast(ring1, rb, m);
                 } else {
-                    box4_gen(ring1, 0, g1, xint1, ya0, m, ok);
+                    box4_gen(ring1, 0, mkgeo(xs + opaque(lane), cs1), xint1, ya0, m, ok);
                 }
 #pragma unroll
                 for (int t = 0; t < RPW; ++t) {
-                    float mm = ga[t] * m[t].x;
-                    float ak = 1.0f * (m[t].y - mm) * gb[t];
-                    float mb2 = 1.0f * ga[t] * ak;
+                    float mm = gab[t].x * m[t].x;
+                    float ak = 1.0f * (m[t].y - mm) * gab[t].y;
+                    float mb2 = 1.0f * gab[t].x * ak;
                     float bk = 1.0f * m[t].x - mb2;
                     abreg[t] = (f2){ak, bk};
                 }
             }
-            if (i + 1 < NI) {
-                issue_next(i + 1);
-                // the left neighbour's record i+1, if it has been published already
-                if (pred && (seen == FLAG_DONE || seen >= (unsigned)i + 2u)) {
-                    if (hu_on) hreg = ld16_sc1(r_in, (unsigned)(((i + 1) * REC_F2) * 8 + tid * 16));
-                    have_pref = true;
-                }
+            V4_STAMP(10);
+            // all hand-off traffic and the loads of the next iteration at the end of the phase: nothing in this
+            // phase waits for them
+            // the left neighbour's record i+1, if it has been published already
+            if (i + 1 < NI && pred && (seen == FLAG_DONE || seen >= (unsigned)i + 2u)) {
+                fetch_rec(i + 1);
+                have_pref = true;
             }
-            V4_STAMP(4);
+            if (succ && (hu_halo || hu_carry)) {
+                // record i: row carries of this iteration's row scans, last 2R+1 columns of the stage-2 integral
+                f4 hov;
+                if (hu_carry) {
+                    hov = *(const f4*)(&cout[0][0] + 2 * (qt - NHALO_U));   // cout[0][0 .. BH), cout[1][0 .. BH) are contiguous
+                } else {
+                    int hu_r, hu_c;
+                    hu_rc(hu_r, hu_c);
+                    int rr = rbp + hu_r;
+                    rr = rr >= RR ? rr - RR : rr;
+                    const f2* p = ring2 + rr * PITCH + OW + hu_c;
+                    const f2 a = p[0], b = p[1];
+                    hov = (f4){a.x, a.y, b.x, b.y};
+                }
+                st16_sc1(r_out, (unsigned)((i * REC_F2) * 8) + hu_off(), hov);
+            }
+            if (i + 1 < NI) issue_guid(i + 1);
+            V4_STAMP(7);
             wg_barrier();
             rbp = rb;
             rb += BH;
@@ -847,7 +1101,7 @@ static V4Layout v4_layout(int w, int h, int R) {
     V4Layout L;
     L.K = (w + R + v4::OW - 1) / v4::OW;
     L.NI = (h - 1 + 2 * R) / v4::BH + 2;     // the q rows of iteration i end at BH i - 2R
-    L.fg = (size_t)(w + 2) * h;
+    L.fg = (size_t)(w + 2 * v4::PADX) * h;
     L.plane = (size_t)w * h;
     L.sv_hand = (size_t)2 * L.NI * v4::REC_F2 * 2;   // parity x records x float2
     return L;
@@ -868,8 +1122,8 @@ size_t v4_workspace_bytes(int w, int h, int nslices) {
     V4Layout L = v4_layout(w, h, v4::RMAX);
     size_t b = 256;
     b += 2 * align_up(L.fg * 4, 256);                               // both image planes (single-view calls too)
-    b += 2 * align_up(L.plane * 4, 256);                            // mean_I, 1/(var+eps)
-    b += 3 * align_up(L.plane * 4, 256);                            // guidance scratch: im, im^2 / S_sq, S_im
+    b += align_up(L.plane * 8, 256);                                // (mean_I, 1/(var+eps))
+    b += 2 * align_up(L.plane * 4, 256);                            // guidance scratch: integrals of I, I*I
     b += (size_t)nslices * align_up(L.plane * 4, 256);              // q
     b += align_up((size_t)nslices * L.sv_hand * 4, 256);
     b += v4_flag_bytes(L, 2 * nslices);                             // control block (shared by both views)
@@ -896,6 +1150,13 @@ extern "C" __attribute__((visibility("default"))) int smx_debug_read_itemlog(uns
     const int m = 3 * v4::ITEMLOG_MAX;
     SMX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(v4::g_itemlog), sizeof(unsigned long long) * (n < m ? n : m)));
     return SMX_OK;
+}
+#endif
+#ifdef SMX_V4_DUMP
+extern "C" __attribute__((visibility("default"))) int smx_debug_read_dump(float* out, int n) {
+    const int m = 2 * 2 * v4::RR * v4::PITCH;
+    SMX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(v4::g_dump), sizeof(float) * (n < m ? n : m)));
+    return m;
 }
 #endif
 #ifdef SMX_V4_STAMPS
@@ -925,7 +1186,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     const V4Layout L = v4_layout(w, h, R);
     const bool use_cost = d_cost && d_cost[0];
     // every plane is addressed through 32-bit buffer offsets, with 0x80000000 as "outside the image"
-    if ((size_t)h * ((size_t)w + 2) * 4 >= 0x80000000ull)
+    if ((size_t)h * ((size_t)w + 2 * v4::PADX) * 8 >= 0x80000000ull)
         return fail(SMX_E_ARG, "aggregate_v4: an image plane of %d x %d exceeds 2 GiB", w, h);
     if (use_cost && nviews == 2 && !d_cost[1])
         return fail(SMX_E_ARG, "aggregate_v4: both views need a cost volume or none");
@@ -946,10 +1207,11 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     SMX_HIP(hipMemsetAsync(status, 0, 256, st));
     // fixed part: image planes, guidance statistics, guidance scratch
     v4::fg_t* FG[2];
-    float *meanI[2], *cinv[2], *gs[3];
+    float* gs[4];
+    v4::f2* gpair[2];
     for (int i = 0; i < 2; ++i) FG[i] = (v4::fg_t*)carve(L.fg * 4);
-    for (int v = 0; v < nviews; ++v) { meanI[v] = (float*)carve(L.plane * 4); cinv[v] = (float*)carve(L.plane * 4); }
-    for (int i = 0; i < 3; ++i) gs[i] = (float*)carve(L.plane * 4);
+    for (int v = 0; v < nviews; ++v) gpair[v] = (v4::f2*)carve(L.plane * 8);
+    for (int i = 0; i < 2 * nviews; ++i) gs[i] = (float*)carve(L.plane * 4);
     const int total = s_end - s_begin;
     // per slice-view: q plane (unless the caller's volume is written directly) + records + flags
     const bool own_q = !(d_agg && d_agg[0]);
@@ -975,17 +1237,25 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     pa.I[1] = nviews == 2 ? d_guide[1] : (d_other ? d_other[0] : nullptr);
     pa.FG[0] = FG[0]; pa.FG[1] = FG[1];
     const int nimg = pa.I[1] ? 2 : 1;
-    hipLaunchKernelGGL(v4::k_v4_prep, dim3(cdivu4(w + 2, 256), h, nimg), dim3(256), 0, st, pa, w, h);
+    hipLaunchKernelGGL(v4::k_v4_prep, dim3(cdivu4(w + 2 * v4::PADX, 256), h, nimg), dim3(256), 0, st, pa, w, h);
     SMX_HIP(hipGetLastError());
     ++nl;
 
-    // ---- guidance statistics (guidedFilter.cu:58-123): mean_I, 1/(var_I + eps), optional u8 mean image
-    for (int v = 0; v < nviews; ++v) {
-        if ((rc = launch_guid_prep(d_guide[v], gs[0], gs[1], (int64_t)L.plane, st))) return rc;
-        if ((rc = launch_integral(2, gs[0], gs[1], gs[2], gs[1], w, h, 1, st))) return rc;
-        if ((rc = launch_guid_finish(p, gs[2], gs[1], meanI[v], cinv[v], d_mean_u8 ? d_mean_u8[v] : nullptr, w, h, st)))
-            return rc;
-        nl += 4;
+    // ---- guidance statistics (guidedFilter.cu:58-123): (mean_I, 1/(var_I + eps)), optional u8 mean image
+    {
+        v4::GuidArgs ga;
+        memset(&ga, 0, sizeof(ga));
+        for (int v = 0; v < nviews; ++v) {
+            ga.FG[v] = FG[v];
+            ga.S[v][0] = gs[2 * v]; ga.S[v][1] = gs[2 * v + 1];
+            ga.G[v] = gpair[v];
+            ga.mean_u8[v] = d_mean_u8 ? d_mean_u8[v] : nullptr;
+        }
+        hipLaunchKernelGGL(v4::k_v4_guid_rows, dim3(cdivu4(h, v4::GR_ROWS), nviews), dim3(64), 0, st, ga, w, h);
+        hipLaunchKernelGGL(v4::k_v4_guid_cols, dim3(cdivu4(w, 64), 2, nviews), dim3(64), 0, st, ga, w, h);
+        hipLaunchKernelGGL(v4::k_v4_guid_finish, dim3(cdivu4(w, 256), h, nviews), dim3(256), 0, st, ga, w, h, R, p->eps);
+        SMX_HIP(hipGetLastError());
+        nl += 3;
     }
 
     v4::Args a0;
@@ -994,7 +1264,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     a0.cc = make_cost_const(p);
     for (int v = 0; v < nviews; ++v) {
         a0.v[v].FG1 = FG[v]; a0.v[v].FG2 = FG[v ^ 1];
-        a0.v[v].mean = meanI[v]; a0.v[v].cinv = cinv[v];
+        a0.v[v].guid = gpair[v];
     }
     for (int s0 = s_begin; s0 < s_end; s0 += chunk) {
         const int cnt = (s_end - s0) < chunk ? (s_end - s0) : chunk;

@@ -1,9 +1,7 @@
 #!/bin/bash
-# dev tool: build a variant of libsmx_hip.so into _build_exp/<name>/ with extra flags
+# dev tool: build a variant of libsmx_hip.so into _build_exp/<name>/ with extra flags ON TOP of the product
+# flags of csrc/Makefile (so a variant differs from the product build by exactly those flags)
 set -e
 ROOT=$(cd $(dirname $0)/.. && pwd); NAME=$1; shift
 OUT=$ROOT/stereo_matching_cuda_amd/_build_exp/$NAME; mkdir -p $OUT
-cd $ROOT/stereo_matching_cuda_amd/csrc
-FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -mllvm -amdgpu-atomic-optimizer-strategy=None -fvisibility=hidden -I$ROOT/include $*"
-for f in smx_kernels smx_agg_v3 smx_capi; do /opt/rocm/bin/hipcc $FL -c $f.hip -o $OUT/$f.o & done; wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libsmx_hip.so $OUT/*.o
+make -s -C $ROOT/stereo_matching_cuda_amd/csrc OUT=$OUT EXTRA="$*" $OUT/libsmx_hip.so

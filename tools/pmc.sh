@@ -24,7 +24,7 @@ for f in glob.glob("$OUT/p*/*/*counter_collection.csv"):
         cnt[k][r["Counter_Name"]] += 1
 with open("$OUT/summary.txt", "w") as o:
     for k in sorted(agg):
-        if "v3" not in k: continue
+        if "walk" not in k and "wta" not in k: continue
         o.write(k + "\n")
         for c in sorted(agg[k]):
             o.write(f"   {c:28s} per-dispatch {agg[k][c]/cnt[k][c]:16.1f}  (n={cnt[k][c]})\n")

@@ -27,6 +27,10 @@ def run(w, h, D, seed, want_agg=True):
             idx = np.argwhere(bad)
             print(f"  {k}: {nb} mismatches of {bad.size}; first {idx[:4].tolist()} "
                   f"rows {idx[:,-2].min()}..{idx[:,-2].max()} cols {idx[:,-1].min()}..{idx[:,-1].max()}")
+            if a.dtype == np.float32 and "-v" in sys.argv:
+                i0 = tuple(idx[0])
+                print("    got", a[i0[:-1]][i0[-1]:i0[-1] + 6], "\n    ref", b[i0[:-1]][i0[-1]:i0[-1] + 6],
+                      "max abs diff", float(np.nanmax(np.abs(a - b))))
     print(f"{w}x{h} D={D}: {'OK' if ok else 'MISMATCH'}", flush=True)
     return ok
 
