@@ -49,7 +49,13 @@ constexpr int HWMAX = 2 * RMAX + 1;     // halo / overlap columns
 constexpr int TWMAX = OW + HWMAX;       // ring columns in use (83 at R = 9)
 constexpr int PITCH = 85;               // float2 per ring row: odd, so the LANE = ROW dword accesses of the row
                                         // scan (row stride 2 PITCH dwords) hit distinct banks
-constexpr int NT = 1024;
+#ifndef SMX_V3_NT
+#define SMX_V3_NT 1024
+#endif
+#ifndef SMX_V3_WGPCU
+#define SMX_V3_WGPCU 1
+#endif
+constexpr int NT = SMX_V3_NT;
 constexpr int NWAVE = NT / 64;
 constexpr int W_R = 0;                  // row-scan wave
 constexpr int W_C = 1;                  // column-scan wave (ring columns 0 .. 63)
@@ -257,7 +263,7 @@ static_assert(BH == 2 * NWB, "every box wave owns two rows of a band");
 static_assert(BH % 2 == 0 && BH / 2 <= 16, "the row scan maps half of the rows to 16 lanes of each half wave");
 
 template <int MODE, int SRC>
-__global__ __launch_bounds__(NT) void k_v3_walk(Args A) {
+__global__ __launch_bounds__(NT, (SMX_V3_WGPCU * (NT / 64) + 3) / 4) void k_v3_walk(Args A) {
     __shared__ __attribute__((aligned(16))) f2 ring1[RR * PITCH];
     // ring 1 keeps stage-1 row y at ring row y mod RR; ring 2 keeps a/b row y at (y + R) mod RR, so that the
     // R-lagged bands of stage 2 start at a band slot like those of stage 1 and never wrap inside a band
@@ -1230,7 +1236,8 @@ static int launch_walk3(const v3::Args& a, hipStream_t st) {
     int dev = 0, ncu = 256;
     SMX_HIP(hipGetDevice(&dev));
     SMX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    const int grid = a.nitems < ncu ? a.nitems : ncu;   // persistent: one workgroup per CU
+    const int slots = SMX_V3_WGPCU * ncu;
+    const int grid = a.nitems < slots ? a.nitems : slots;   // persistent: SMX_V3_WGPCU workgroup(s) per CU
     hipLaunchKernelGGL((v3::k_v3_walk<MODE, SRC>), dim3((unsigned)grid), dim3(v3::NT), 0, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;

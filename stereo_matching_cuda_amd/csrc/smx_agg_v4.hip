@@ -33,6 +33,7 @@
 // and a workgroup barrier; no acquire fence).
 //
 // Must be compiled with -ffp-contract=off.
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -47,16 +48,28 @@ constexpr int OW = 64;                  // output columns per strip = one wave
 constexpr int RMAX = 9;                 // largest supported box radius
 constexpr int HWMAX = 2 * RMAX + 1;     // halo / overlap columns
 constexpr int TWMAX = OW + HWMAX;       // ring columns in use (83 at R = 9)
-constexpr int PITCH = 85;               // float2 per ring row: odd, so the LANE = ROW dword accesses of the row
-                                        // scan (row stride 2 PITCH dwords = 10 mod 32) hit distinct banks
+// A ring row is component-planar: ROWF floats = the first components (p / a) of its columns at [0, OFF1), the
+// second ones (I p / b) at [OFF1, OFF1 + NCOLP).  The row scan then moves four columns of one component per LDS
+// instruction (16-byte aligned: ROWF, OFF1 are multiples of 4), the LANE = COLUMN phases read a cell's pair with
+// one ds_read2_b32.  Row stride 172 dwords = 12 mod 32: the 16-byte stores of 8 consecutive rows hit distinct banks.
+constexpr int NCOLP = 84;               // columns per component plane of a row (TWMAX rounded up to quads)
+constexpr int OFF1 = 88;
+constexpr int ROWF = OFF1 + NCOLP;      // 172
+static_assert(NCOLP >= TWMAX && NCOLP % 4 == 0 && OFF1 % 4 == 0 && OFF1 >= NCOLP, "planar ring row");
 constexpr int NT = 512;
 constexpr int NWAVE = NT / 64;
-constexpr int BH = 32;                  // band height
+// Band height: 32 rows (rings of 52 rows, 72 KB of LDS, two workgroups per CU) or 16 rows (rings of 36 rows,
+// 50 KB, three workgroups per CU, fewer idle rows at the bottom of a strip)
+#ifndef SMX_V4_BH
+#define SMX_V4_BH 16
+#endif
+constexpr int BH = SMX_V4_BH;           // band height
 constexpr int RPW = BH / NWAVE;         // rows of a band per wave in the LANE = COLUMN phases
-constexpr int RR = 52;                  // ring rows
-static_assert(RR >= BH + 2 * RMAX + 2, "a band of box means needs BH + 2R + 1 rows");
-static_assert(RR % RPW == 0 && BH % RPW == 0, "a wave's group of RPW consecutive ring rows never wraps");
-static_assert(RPW == 4, "the box / cost code below is written for four rows per wave");
+constexpr int RR = BH + 2 * RMAX + 2;   // ring rows: a band of box means needs BH + 2R + 1 rows
+constexpr int WG_PER_CU = BH == 32 ? 2 : 3;
+static_assert(BH == 32 || BH == 16, "band height");
+static_assert(RR % 4 == 0 && RR % RPW == 0 && BH % RPW == 0 && RPW % 2 == 0,
+              "groups of four (column scan) and of RPW (box, cost) consecutive ring rows never wrap");
 
 enum Src { SRC_IMG = 0, SRC_COST = 1 };
 
@@ -327,7 +340,8 @@ static_assert(REC_U <= NT && HP % 2 == 0 && BH % 2 == 0, "one 16-byte hand-off u
 constexpr int NQ = (TWMAX + 3) / 4;               // quads per ring row (21; the last one ends in the pitch padding)
 constexpr int QW0 = 2;                            // first wave that holds quads
 constexpr int QTH = NT - 64 * QW0;                // threads that hold quads
-static_assert(NQ * 4 <= PITCH && NQ <= 4 * (NWAVE - QW0) && BH == 32, "two quads (rows r, r + 16) per quad-holding thread");
+constexpr int NQR = BH / 16;                      // quads per quad-holding thread: rows r, r + 16, ..
+static_assert(NQ * 4 <= NCOLP && NQ <= 4 * (NWAVE - QW0), "one wave-instruction covers 16 rows x 4 quads");
 
 // Diagnostic build only (-DSMX_V4_STAMPS=<item>): every wave of one work item records the shader clock
 // at its phase boundaries; the product build contains no stamp.
@@ -346,13 +360,13 @@ __device__ unsigned long long g_stamps[NWAVE * STAMP_SLOTS];
 // Diagnostic build only (-DSMX_V4_DUMP=<item> -DSMX_V4_DUMP_IT=<iteration> -DSMX_V4_DUMP_PH=<0..3: behind the
 // barrier that ends W / R / C / X>): both LDS rings of one work item at one point -> global memory
 #ifdef SMX_V4_DUMP
-__device__ float g_dump[2 * 2 * RR * PITCH];
+__device__ float g_dump[2 * RR * ROWF];
 #define V4_DUMP(ph)                                                                               \
     do {                                                                                          \
         if (item == SMX_V4_DUMP && i == SMX_V4_DUMP_IT && (ph) == SMX_V4_DUMP_PH) {                \
-            for (int e_ = tid; e_ < 2 * RR * PITCH; e_ += NT) {                                    \
-                g_dump[e_] = ((const float*)ring1)[e_];                                            \
-                g_dump[2 * RR * PITCH + e_] = ((const float*)ring2)[e_];                           \
+            for (int e_ = tid; e_ < RR * ROWF; e_ += NT) {                                         \
+                g_dump[e_] = ring1[e_];                                                            \
+                g_dump[RR * ROWF + e_] = ring2[e_];                                                \
             }                                                                                     \
             wg_barrier();                                                                         \
         }                                                                                         \
@@ -379,9 +393,9 @@ __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(s
 
 // RT: compile-time box radius (RMAX) or -1 = the radius of the call (A.R <= RMAX)
 template <int SRC, int RT>
-__global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
-    __shared__ __attribute__((aligned(16))) f2 ring1[RR * PITCH];   // stage-1 row y at ring row y mod RR
-    __shared__ __attribute__((aligned(16))) f2 ring2[RR * PITCH];   // a/b row y at ring row (y + R) mod RR
+__global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
+    __shared__ __attribute__((aligned(16))) float ring1[RR * ROWF];   // stage-1 row y at ring row y mod RR
+    __shared__ __attribute__((aligned(16))) float ring2[RR * ROWF];   // a/b row y at ring row (y + R) mod RR
     __shared__ __attribute__((aligned(16))) f2 cout[2][BH];         // row carries out
     __shared__ float rcp_s[HWMAX * HWMAX + 1];                      // RN(1/area)
     __shared__ int s_item, s_next;
@@ -417,15 +431,16 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
     // row-scan lanes: each 32-lane group (the unit of LDS banking for dword accesses) takes half of the rows
     // with both components, lanes 0-15 / 16-31 = first / second component: 16 distinct even + 16 distinct
     // odd banks (row stride 170 dwords = 10 mod 32)
-    auto srow_of = [&]() { const int l = opaque(lane); return (l & 15) + 16 * (l >> 5); };
+    // BH = 32: wave 0 scans stage 1, wave 1 stage 2; BH = 16: wave 0 scans both, lanes 32.. = stage 2
+    auto srow_of = [&]() { const int l = opaque(lane); return BH == 32 ? (l & 15) + 16 * (l >> 5) : (l & 15); };
     auto scomp_of = [&]() { return (opaque(lane) >> 4) & 1; };
+    auto sstage_of = [&]() { return BH == 32 ? wave : (opaque(lane) >> 5); };
+    constexpr int NRSW = BH == 32 ? 2 : 1;      // row-scan waves
     // this thread's two stage-1 input quads (waves QW0..): row of the band, first ring column
     // One wave-instruction covers 16 rows x 4 quads: the LDS writes of a 16-lane group then go to 16 different
     // rows (row stride 170 dwords = 10 mod 32: conflict-free), the global loads to 64-byte runs of 16 rows.
     // Wave QW0 + g takes the quads 4g .. 4g+3 of a row; its two rounds the rows 0..15 / 16..31 of the band.
-    bool q_on[2];
-#pragma unroll
-    for (int e = 0; e < 2; ++e) q_on[e] = wave >= QW0 && 4 * (wave - QW0) + (lane >> 4) < NQ;
+    const bool q_on = wave >= QW0 && 4 * (wave - QW0) + (lane >> 4) < NQ;
     auto quad_rc = [&](int e, int& r, int& c) {
         const int l = opaque(lane);
         r = 16 * e + (l & 15);
@@ -497,13 +512,13 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
 
         // stage-1 inputs of the next band: raw quads (four (value, gradient) cells of this view / of the other view,
         // or four raw costs), loaded in W(i); evaluated to (p, I p) under the row scans of R(i); written in W(i+1)
-        u4 qa[2], qb[2];
-        f2 qres[2][4];
+        u4 qa[NQR], qb[NQR];
+        f2 qres[NQR][4];
         f2 gab[RPW];                         // (mean_I, 1/(var+eps)) of the a/b rows of the next X phase
         uint32_t Iraw[RPW];                  // raw (value, gradient) halves of the q rows of the next X phase
         f2 abreg[RPW];                       // a_k, b_k of this wave's rows, written to ring 2 in the next W phase
-        f4 hreg = {0, 0, 0, 0};              // this thread's halo unit of the left neighbour's next record (waves QW0..)
-        float creg = -0.0f;                  // this row-scan lane's carry of the left neighbour's next record (waves 0, 1)
+        f4 hreg = {0, 0, 0, 0};              // this thread's unit of the left neighbour's next record: a halo unit (waves
+                                             // QW0..) or the unit with this row-scan lane's carry
         bool have_pref = false;
         unsigned seen = 0;
 #pragma unroll
@@ -511,10 +526,9 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
 
         // loads of the stage-1 inputs of band ib (rows clamped into the image: every load is issued)
         auto issue_cost = [&](int ib) {
-            if (wave < QW0) return;
+            if (!q_on) return;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                if (!q_on[e]) continue;
+            for (int e = 0; e < NQR; ++e) {
                 int qr, qc;
                 quad_rc(e, qr, qc);
                 // a quad wholly outside the image is moved onto the sentinel columns (its cells are written but
@@ -538,10 +552,9 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
         };
         // raw -> (p, I p)
         auto eval_cost = [&]() {
-            if (wave < QW0) return;
+            if (!q_on) return;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                if (!q_on[e]) continue;
+            for (int e = 0; e < NQR; ++e) {
                 const unsigned ra[4] = {qa[e].x, qa[e].y, qa[e].z, qa[e].w};
                 const unsigned rb4[4] = {qb[e].x, qb[e].y, qb[e].z, qb[e].w};
 #pragma unroll
@@ -579,13 +592,13 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
         };
 
         // loads of this thread's part of the left neighbour's record `rec` (sc1: the hand-off form of the guide)
+        // One 16-byte load per thread, without a branch (a load under a condition makes the compiler merge old and
+        // new register values right behind it, i.e. wait for it on the spot): the halo unit of a thread of waves
+        // QW0.., the unit that holds its carry for a row-scan lane (any unit for the others: never used).
         auto fetch_rec = [&](int rec) {
             const unsigned base = (unsigned)(rec * REC_F2 * 8);
-            if (wave < QW0)
-                creg = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                           r_in, (int)(base + (unsigned)((wave * BH + srow_of()) * 8 + scomp_of() * 4)), 0, AUX_SC1));
-            else if (hu_halo)
-                hreg = ld16_sc1(r_in, base + hu_off());
+            const unsigned coff = (unsigned)(((sstage_of() * BH + srow_of()) * 8) & ~15);
+            hreg = ld16_sc1(r_in, base + (wave < NRSW ? coff : (hu_halo ? hu_off() : 0u)));
         };
         // bounded wait for the left neighbour's flag >= need (thread 0 only); result -> s_seen
         auto spin_pred = [&](unsigned need) {
@@ -604,45 +617,65 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
             }
         };
 
-        // ---- row scan of one band: this lane = one component of one row ------------------------------------
-        auto rowscan = [&](f2* ring, int st, int rbase, int yband, int jlo, int jhi, bool full, auto NCOL) {
-            constexpr int NC = decltype(NCOL)::value;      // columns of the unrolled form
-            const int srow = srow_of(), scomp = scomp_of();
-            const int y = yband + srow;
-            if (y < 0 || y >= h || jhi <= jlo) return;
-            int rr = rbase + srow;
+        // ---- row scans of iteration i: this lane = one component of one row of one stage --------------------
+        // stage 1: band i, ring-1 columns [jlo1, jhi1); stage 2: a/b band i-1, the new ring-2 columns [jlo2, jhi2)
+        auto rowscans = [&](int i, int rb, int rbp) {
+            const int st = sstage_of(), srow = srow_of(), scomp = scomp_of();
+            const int y = st == 0 ? BH * i + srow : BH * (i - 1) - R + srow;
+            const int jlo = st == 0 ? jlo1 : jlo2, jhi = st == 0 ? jhi1 : jhi2;
+            const bool act = y >= 0 && y < h && jhi > jlo && (st == 0 || i >= 1);
+            int rr = (st == 0 ? rb : rbp) + srow;
             rr = rr >= RR ? rr - RR : rr;
-            float acc = pred ? creg : -0.0f;
-            float* row = (float*)(ring + rr * PITCH) + scomp;   // column c of this component: row[2 c]
-            if (full) {
-                // the common case: NC columns from jlo, fully unrolled so that every LDS wait is a counted one;
-                // the reads run one batch of 8 columns ahead of the adds
-                float* r0 = row + 2 * jlo;
-                constexpr int NBATCH = NC / 8;
-                float v[2][8];
+            // the unit holds the carries (p, I p) / (a, b) of rows 2k, 2k+1
+            const float c01 = scomp ? hreg.y : hreg.x, c23 = scomp ? hreg.w : hreg.z;
+            float acc = pred ? ((srow & 1) ? c23 : c01) : -0.0f;
+#ifdef SMX_V4_STAMPS
+            asm volatile("" : "+v"(acc));
+            V4_STAMP(11);
+#endif
+            float* row = (st == 0 ? ring1 : ring2) + rr * ROWF + scomp * OFF1;   // column c of this component: row[c]
+            float* const co = (float*)&cout[st][srow] + scomp;
+            // NG groups of four columns from group G0, unrolled; the reads run two groups ahead of the adds.
+            // hook(g) runs behind group g.
+            auto run4 = [&](auto G0c, auto NGc, auto hook) {
+                constexpr int G0 = decltype(G0c)::value, NG = decltype(NGc)::value;
+                f4* const r4 = (f4*)row;
+                f4 v[3];
+                f4 xo[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+                v[0] = r4[G0];
+                if (NG > 1) v[1] = r4[G0 + 1];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) v[0][t] = r0[2 * t];
-#pragma unroll
-                for (int bt = 0; bt < NBATCH; ++bt) {
-                    if (bt + 1 < NBATCH) {
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) v[(bt + 1) & 1][t] = r0[2 * (8 * (bt + 1) + t)];
-                    }
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        acc = v[bt & 1][t] + acc;
-                        r0[2 * (8 * bt + t)] = acc;
-                        if (st == 0 && 8 * bt + t == OW - 1) ((float*)&cout[0][srow])[scomp] = acc;
-                    }
+                for (int g = 0; g < NG; ++g) {
+                    if (g + 2 < NG) v[(g + 2) % 3] = r4[G0 + g + 2];
+                    const f4 in = v[g % 3];
+                    f4& x = xo[g & 1];
+                    acc = in.x + acc; x.x = acc;
+                    acc = in.y + acc; x.y = acc;
+                    acc = in.z + acc; x.z = acc;
+                    hook(G0 + g, acc);
+                    acc = in.w + acc; x.w = acc;
+                    r4[G0 + g] = x;
+                    // The sums of two consecutive groups live in different registers: the adds of a group then do not
+                    // have to wait until the 16-byte store of the previous one has read its four source registers.
+                    asm volatile("" :: "v"(xo[(g & 1) ^ 1]));
                 }
-#pragma unroll
-                for (int c = 8 * NBATCH; c < NC; ++c) {
-                    acc = r0[2 * c] + acc;
-                    r0[2 * c] = acc;
+            };
+            if (RT == RMAX && jlo1 == 0 && jhi1 == TWMAX && jhi2 == TWMAX) {
+                // the common case (a strip inside the image at radius 9): stage 1 scans ring columns 0 .. 82 (and
+                // the unused column 83), stage 2 the columns 19 .. 82; the carry for the next strip is the running
+                // sum behind ring column 63 (stage 1) / behind column 82 (stage 2)
+                static_assert(HWMAX == 19 && OW == 64 && TWMAX == 83, "group boundaries below");
+                if (act && st == 0) run4(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{}, [](int, float) {});
+                if (act && st == 1) { acc = row[HWMAX] + acc; row[HWMAX] = acc; }    // (columns 16 .. 18 are the neighbour's)
+                if (act) {
+                    run4(std::integral_constant<int, 5>{}, std::integral_constant<int, 11>{}, [](int, float) {});
+                    if (st == 0) *co = acc;                                           // behind column 63
+                    run4(std::integral_constant<int, 16>{}, std::integral_constant<int, 5>{},
+                         [&](int g, float a) { if (g == 20 && st == 1) *co = a; });   // behind column 82
                 }
-                if (st == 1) ((float*)&cout[1][srow])[scomp] = acc;
                 return;
             }
+            if (!act) return;
             // general strip: batches of 8 columns, ping-pong; the reads of the next batch are always issued
             // (past the end they fetch bytes nobody uses: LDS reads cannot fault)
             int j = jlo;
@@ -650,62 +683,58 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
             float va[8], vb[8];
             auto rd = [&](float (&v)[8], int c) {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) v[t] = row[2 * (c + t)];
+                for (int t = 0; t < 8; ++t) v[t] = row[c + t];
             };
-            auto run = [&](const float (&v)[8], int c) {
+            auto runb = [&](const float (&v)[8], int c) {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     acc = v[t] + acc;
-                    row[2 * (c + t)] = acc;
+                    row[c + t] = acc;
                 }
             };
             if (nb8 > 0) rd(va, j);
             int b = 0;
             for (; b + 2 <= nb8; b += 2) {
                 rd(vb, j + 8);
-                run(va, j);
+                runb(va, j);
                 rd(va, j + 16);
-                run(vb, j + 8);
+                runb(vb, j + 8);
                 j += 16;
             }
             if (b < nb8) {
-                run(va, j);
+                runb(va, j);
                 j += 8;
             }
             for (; j < jhi; ++j) {
-                acc = row[2 * j] + acc;
-                row[2 * j] = acc;
+                acc = row[j] + acc;
+                row[j] = acc;
             }
             // running row sum left of the next strip's first column (stage 1: ring column OW-1; stage 2: the last one)
-            if (st == 0) { if (OW - 1 >= jlo && OW - 1 < jhi) ((float*)&cout[0][srow])[scomp] = row[2 * (OW - 1)]; }
-            else ((float*)&cout[1][srow])[scomp] = acc;
+            if (st == 0) { if (OW - 1 >= jlo && OW - 1 < jhi) *co = row[OW - 1]; }
+            else *co = acc;
         };
 
         // ---- column scan of one band for the dword `idx` (column, component) of this lane -------------------
         // rows yband + t at ring rows (rbase + t) mod RR; groups of four rows never wrap (RR % 4 == 0)
-        auto colscan = [&](f2* ring, int idx, int rbase, int yband, float& S) {
-            float* const pc = (float*)ring + idx;
-            constexpr int P2 = 2 * PITCH;
+        auto colscan = [&](float* ring, int idx, int rbase, int yband, float& S) {
+            float* const pc = ring + idx;
+            constexpr int P2 = ROWF;
             if (yband >= 0 && yband + BH <= h) {
-                // full band: all reads in flight, then the dependent chain of adds with its writes
-                float v[BH];
-                float* pg[BH / 4];
-                int rr = rbase;
-#pragma unroll
-                for (int g = 0; g < BH / 4; ++g) {
-                    pg[g] = pc + rr * P2;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) v[4 * g + t] = pg[g][t * P2];
-                    rr += 4;
+                // full band: up to 16 rows of reads in flight ahead of the dependent chain of adds and its writes
+                auto rowp = [&](int t) {
+                    int rr = rbase + (t & ~3);
                     rr = rr >= RR ? rr - RR : rr;
-                }
+                    return pc + rr * P2 + (t & 3) * P2;
+                };
+                constexpr int NPF = BH < 16 ? BH : 16;
+                float v[NPF];
 #pragma unroll
-                for (int g = 0; g < BH / 4; ++g) {
+                for (int t = 0; t < NPF; ++t) v[t] = *rowp(t);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        S = v[4 * g + t] + S;
-                        pg[g][t * P2] = S;
-                    }
+                for (int t = 0; t < BH; ++t) {
+                    S = v[t % NPF] + S;
+                    *rowp(t) = S;
+                    if (t + NPF < BH) v[t % NPF] = *rowp(t + NPF);
                 }
                 return;
             }
@@ -723,39 +752,21 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
         // S01 + S00 in that order, then a true division by the window area) ---------------------------------
         // fast form: every window of the band is unclipped in x and y.  rbase = ring row of the band's first
         // bottom tap row (the top tap row is 2R+1 ring rows above it).
-        auto box2_fast = [&](const f2* ring, int rbase, int half, f2* m) {
+        // a cell's (first, second) component: one ds_read2_b32
+        auto cell = [&](const float* p) { return (f2){p[0], p[OFF1]}; };
+        auto box2_fast = [&](const float* ring, int rbase, int half, f2* m) {
             int rb0 = rbase + RPW * wave;
-            rb0 = rb0 >= RR ? rb0 - RR : rb0;            // the wave's group of four bottom rows never wraps
+            rb0 = rb0 >= RR ? rb0 - RR : rb0;            // the wave's group of RPW bottom rows never wraps
             rb0 += 2 * half;
             f2 s11[2], s10[2], s01[2], s00[2], val[2];
-            if (RT == RMAX) {
-                constexpr int HWB = (2 * (RT >= 0 ? RT : 0) + 1) * 8;
-                const unsigned ab = lds_off(ring + rb0 * PITCH + lane);
-                int rt0 = rb0 - HW, rt1 = rb0 + 1 - HW;
-                rt0 = rt0 < 0 ? rt0 + RR : rt0;
-                rt1 = rt1 < 0 ? rt1 + RR : rt1;
-                const unsigned at0 = lds_off(ring + rt0 * PITCH + lane), at1 = lds_off(ring + rt1 * PITCH + lane);
-                LDS_RD64(s11[0], ab, HWB);
-                LDS_RD64(s10[0], ab, 0);
-                LDS_RD64(s01[0], at0, HWB);
-                LDS_RD64(s00[0], at0, 0);
-                LDS_RD64(s11[1], ab, PITCH * 8 + HWB);
-                LDS_RD64(s10[1], ab, PITCH * 8);
-                LDS_RD64(s01[1], at1, HWB);
-                LDS_RD64(s00[1], at1, 0);
-                asm volatile("s_waitcnt lgkmcnt(0)"
-                             : "+v"(s11[0]), "+v"(s10[0]), "+v"(s01[0]), "+v"(s00[0]), "+v"(s11[1]), "+v"(s10[1]), "+v"(s01[1]),
-                               "+v"(s00[1]));
-            } else {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    int rt = rb0 + t - HW;
-                    rt = rt < 0 ? rt + RR : rt;
-                    const f2* pb = ring + (rb0 + t) * PITCH + lane;
-                    const f2* pt = ring + rt * PITCH + lane;
-                    s11[t] = pb[HW]; s10[t] = pb[0];
-                    s01[t] = pt[HW]; s00[t] = pt[0];
-                }
+            for (int t = 0; t < 2; ++t) {
+                int rt = rb0 + t - HW;
+                rt = rt < 0 ? rt + RR : rt;
+                const float* pb = ring + (rb0 + t) * ROWF + lane;
+                const float* pt = ring + rt * ROWF + lane;
+                s11[t] = cell(pb + HW); s10[t] = cell(pb);
+                s01[t] = cell(pt + HW); s00[t] = cell(pt);
             }
             float amin = __builtin_inff(), amax = 0.0f;
 #pragma unroll
@@ -779,15 +790,15 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
                 }
             }
         };
-        auto box4_fast = [&](const f2* ring, int rbase, f2 (&m)[RPW]) {
-            box2_fast(ring, rbase, 0, &m[0]);
-            box2_fast(ring, rbase, 1, &m[2]);
+        auto box4_fast = [&](const float* ring, int rbase, f2 (&m)[RPW]) {
+#pragma unroll
+            for (int hf = 0; hf < RPW / 2; ++hf) box2_fast(ring, rbase, hf, &m[2 * hf]);
         };
         // general form: windows clipped at the image borders; rows y0 + t that do not exist are skipped
         // (ok[t] = false).  shift = 0 (ring 1) or R (ring 2).
-        auto box4_gen = [&](const f2* ring, int shift, const Geo& g, bool xint, int y0, f2 (&m)[RPW], bool (&ok)[RPW]) {
-            const f2* const pmax = ring + g.jmax;
-            const f2* const pmin = ring + g.jmin;
+        auto box4_gen = [&](const float* ring, int shift, const Geo& g, bool xint, int y0, f2 (&m)[RPW], bool (&ok)[RPW]) {
+            const float* const pmax = ring + g.jmax;
+            const float* const pmin = ring + g.jmin;
             const bool left = xint || g.hx;
 #pragma unroll
             for (int t = 0; t < RPW; ++t) {
@@ -799,8 +810,8 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
                 const int ymin = y - R - 1;
                 const bool hy = ymin >= 0;
                 const int ych = ymax - (hy ? ymin : -1);
-                const int o1 = ((ymax + shift) % RR) * PITCH, o0 = (((hy ? ymin : 0) + shift) % RR) * PITCH;
-                const f2 s11 = pmax[o1], s10 = pmin[o1], s01 = pmax[o0], s00 = pmin[o0];
+                const int o1 = ((ymax + shift) % RR) * ROWF, o0 = (((hy ? ymin : 0) + shift) % RR) * ROWF;
+                const f2 s11 = cell(pmax + o1), s10 = cell(pmin + o1), s01 = cell(pmax + o0), s00 = cell(pmin + o0);
                 const int ai = (xint ? HW : g.xcw) * ych;
                 const float area = (float)ai, ra = rcp_s[ai];
                 f2 v = s11;
@@ -829,9 +840,9 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
             if (tid == 0) spin_pred(1u);
             wg_barrier();
             seen = s_seen;
-            fetch_rec(0);
-            have_pref = true;
         }
+        fetch_rec(0);
+        have_pref = pred;
         eval_cost();
         float Sc = -0.0f;                   // running column sum of this lane's dword (waves 0..4)
         int rb = 0, rbp = 0;                // ring row of the first row of band i / band i-1 (both rings)
@@ -839,24 +850,27 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
             // ------------------------------------ W(i) --------------------------------------------------
             V4_STAMP(0);
             {
-                if (wave >= QW0) {
+                if (q_on) {
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        if (!q_on[e]) continue;
+                    for (int e = 0; e < NQR; ++e) {
                         int qr, qc;
                         quad_rc(e, qr, qc);
                         int rw = rb + qr;
                         rw = rw >= RR ? rw - RR : rw;
-                        f2* dst = ring1 + rw * PITCH + qc;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) dst[j] = qres[e][j];
+                        float* dst = ring1 + rw * ROWF + qc;
+                        *(f4*)dst = (f4){qres[e][0].x, qres[e][1].x, qres[e][2].x, qres[e][3].x};
+                        *(f4*)(dst + OFF1) = (f4){qres[e][0].y, qres[e][1].y, qres[e][2].y, qres[e][3].y};
                     }
                 }
                 if (i >= 1) {
                     int rw2 = rbp + RPW * wave;
                     rw2 = rw2 >= RR ? rw2 - RR : rw2;
 #pragma unroll
-                    for (int t = 0; t < RPW; ++t) ring2[(rw2 + t) * PITCH + HW + lane] = abreg[t];
+                    for (int t = 0; t < RPW; ++t) {
+                        float* dst = ring2 + (rw2 + t) * ROWF + HW + lane;
+                        dst[0] = abreg[t].x;
+                        dst[OFF1] = abreg[t].y;
+                    }
                 }
                 if (pred && !have_pref) {
                     // the neighbour had not published record i when this item looked: wait for it now
@@ -867,7 +881,7 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
                 }
                 have_pref = false;
             }
-            if (i + 1 < NI) issue_cost(i + 1);      // lands under the row scans
+            issue_cost(i + 1);      // lands under the row scans (rows clamped: harmless behind the last iteration)
             V4_STAMP(1);
             wg_barrier();
             V4_STAMP(2);
@@ -875,16 +889,9 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
             // ------------------------------------ R(i) --------------------------------------------------
             // the scans are dependent chains on the critical path of the iteration: let them win the issue
             // arbitration against the waves (of this and the other workgroup) that share their SIMDs
-            if (wave == 0) {
+            if (wave < NRSW) {
                 __builtin_amdgcn_s_setprio(3);
-                rowscan(ring1, 0, rb, BH * i, jlo1, jhi1, RT == RMAX && jlo1 == 0 && jhi1 == TWMAX,
-                        std::integral_constant<int, TWMAX>{});
-                __builtin_amdgcn_s_setprio(0);
-            } else if (wave == 1) {
-                __builtin_amdgcn_s_setprio(3);
-                if (i >= 1)
-                    rowscan(ring2, 1, rbp, BH * (i - 1) - R, jlo2, jhi2, RT == RMAX && jhi2 == TWMAX,
-                            std::integral_constant<int, OW>{});
+                rowscans(i, rb, rbp);
                 __builtin_amdgcn_s_setprio(0);
             } else {
                 if (wave == NWAVE - 1 && lane == 0) {
@@ -894,7 +901,7 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
                     if (i == NI - 1)
                         s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (i + 1 < NI) eval_cost();
+                eval_cost();
                 // the left neighbour's last 2R+1 columns of the stage-2 integral of band i-1 -> ring 2 (nobody
                 // touches these columns before X(i))
                 int hu_r, hu_c;
@@ -902,9 +909,15 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
                 if (pred && hu_halo && i >= 1 && hu_c < HW) {
                     int rr = rbp + hu_r;
                     rr = rr >= RR ? rr - RR : rr;
-                    f2* dst = ring2 + rr * PITCH + hu_c;
-                    dst[0] = (f2){hreg.x, hreg.y};
-                    if (hu_c + 1 < HW) dst[1] = (f2){hreg.z, hreg.w};
+                    // unit = (first, second) component of column hu_c, then of column hu_c + 1
+                    float* dst = ring2 + rr * ROWF + hu_c;
+                    if (hu_c + 1 < HW) {
+                        *(f2*)dst = (f2){hreg.x, hreg.z};
+                        *(f2*)(dst + OFF1) = (f2){hreg.y, hreg.w};
+                    } else {
+                        dst[0] = hreg.x;
+                        dst[OFF1] = hreg.y;
+                    }
                 }
                 // every storing wave drains its global accesses here: the record stored in X(i-1) is complete in
                 // memory before the barrier behind which one lane publishes it
@@ -919,12 +932,12 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
             // one dword (column, component) of a ring row per lane, lane-linear along the row
             if (wave < 3) {
                 __builtin_amdgcn_s_setprio(3);
-                const int cidx1 = 64 * wave + opaque(lane);                      // stage 1: dwords [0, 2 TW)
-                if (cidx1 < 2 * TW) colscan(ring1, cidx1, rb, BH * i, Sc);
+                const int cidx1 = 64 * wave + opaque(lane);                      // stage 1: every dword of a row
+                if (cidx1 < ROWF) colscan(ring1, cidx1, rb, BH * i, Sc);
                 __builtin_amdgcn_s_setprio(0);
             } else if (wave < 5) {
                 __builtin_amdgcn_s_setprio(3);
-                const int cidx2 = 2 * HW + 64 * (wave - 3) + opaque(lane);       // stage 2: dwords [2 HW, 2 TW)
+                const int cidx2 = OFF1 * (wave - 3) + HW + opaque(lane);         // stage 2: the new columns of either plane
                 if (i >= 1) colscan(ring2, cidx2, rbp, BH * (i - 1) - R, Sc);
                 __builtin_amdgcn_s_setprio(0);
             }
@@ -935,28 +948,19 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
             // ------------------------------------ X(i) --------------------------------------------------
             seen = s_seen;
             V4_STAMP(8);
-            if (i >= 1) {
-                // box means of stage 2 -> q rows [BH (i-1) - 2R, BH i - 2R)
-                const int yq0 = BH * (i - 1) - 2 * R + RPW * wave;
-                f2 m[RPW];
-                bool ok[RPW];
-                if (xint2 && BH * (i - 1) - 3 * R - 1 >= 0 && BH * i - R <= h) {
-                    box4_fast(ring2, rbp, m);
+            // Order of the phase: everything that consumes a value loaded in the previous iteration comes before
+            // the first global access of this one.  (The compiler cannot count loads across the loop edge: the
+            // first such use behind a new access waits for ALL outstanding accesses, the new one included.)
+            // The left neighbour's record i+1 is needed first thing in the next iteration and comes from another
+            // XCD's writes (1 - 2 us): its load goes out at the start of the phase, right behind a "use" of the
+            // values loaded in the previous iteration (they arrived long ago: that wait is free).
 #pragma unroll
-                    for (int t = 0; t < RPW; ++t) ok[t] = true;
-                } else {
-                    box4_gen(ring2, R, mkgeo(xs - R + opaque(lane), cs2), xint2, yq0, m, ok);
-                }
-                const unsigned vq = vq_of();
-#pragma unroll
-                for (int t = 0; t < RPW; ++t) {
-                    const float Iv = (float)__builtin_bit_cast(fg_t, Iraw[t]).x;
-                    float tq = m[t].x * Iv;            // compute_q guidedFilter.cu:363-369
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, tq + m[t].y), r_q, (int)(ok[t] ? vq : OOB),
-                                                          min(max(yq0 + t, 0), h - 1) * (int)w4, AUX_NT);
-                }
-            }
-            V4_STAMP(9);
+            for (int t = 0; t < RPW; ++t) asm volatile("" : "+v"(gab[t]), "+v"(Iraw[t]));
+            // The loads are issued in every iteration of every item: a load under a condition makes the compiler
+            // merge old and new register values right behind it, i.e. wait for it on the spot.  What they return
+            // counts only if the record had been published (have_pref).
+            fetch_rec(min(i + 1, NI - 1));
+            have_pref = pred && (seen == FLAG_DONE || seen >= (unsigned)i + 2u);
             {
                 // box means of stage 1 -> a_k, b_k rows [BH i - R, BH i + BH - R)   (compute_ak_and_bk guidedFilter.cu:345-354)
                 const int ya0 = BH * i - R + RPW * wave;
@@ -976,13 +980,38 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
                     abreg[t] = (f2){ak, bk};
                 }
             }
+            V4_STAMP(9);
+            float qout[RPW];
+            bool qok[RPW];
+            const int yq0 = BH * (i - 1) - 2 * R + RPW * wave;
+#pragma unroll
+            for (int t = 0; t < RPW; ++t) { qout[t] = 0.0f; qok[t] = false; }
+            if (i >= 1) {
+                // box means of stage 2 -> q rows [BH (i-1) - 2R, BH i - 2R)
+                f2 m[RPW];
+                if (xint2 && BH * (i - 1) - 3 * R - 1 >= 0 && BH * i - R <= h) {
+                    box4_fast(ring2, rbp, m);
+#pragma unroll
+                    for (int t = 0; t < RPW; ++t) qok[t] = true;
+                } else {
+                    box4_gen(ring2, R, mkgeo(xs - R + opaque(lane), cs2), xint2, yq0, m, qok);
+                }
+#pragma unroll
+                for (int t = 0; t < RPW; ++t) {
+                    const float Iv = (float)__builtin_bit_cast(fg_t, Iraw[t]).x;
+                    float tq = m[t].x * Iv;            // compute_q guidedFilter.cu:363-369
+                    qout[t] = tq + m[t].y;
+                }
+            }
             V4_STAMP(10);
-            // all hand-off traffic and the loads of the next iteration at the end of the phase: nothing in this
-            // phase waits for them
-            // the left neighbour's record i+1, if it has been published already
-            if (i + 1 < NI && pred && (seen == FLAG_DONE || seen >= (unsigned)i + 2u)) {
-                fetch_rec(i + 1);
-                have_pref = true;
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- the global accesses of the phase: q rows, record i, the loads of iteration i+1 ----
+            if (i >= 1) {
+                const unsigned vq = vq_of();
+#pragma unroll
+                for (int t = 0; t < RPW; ++t)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qout[t]), r_q, (int)(qok[t] ? vq : OOB),
+                                                          min(max(yq0 + t, 0), h - 1) * (int)w4, AUX_NT);
             }
             if (succ && (hu_halo || hu_carry)) {
                 // record i: row carries of this iteration's row scans, last 2R+1 columns of the stage-2 integral
@@ -994,13 +1023,14 @@ __global__ __launch_bounds__(NT, 4) void k_v4_walk(Args A) {
                     hu_rc(hu_r, hu_c);
                     int rr = rbp + hu_r;
                     rr = rr >= RR ? rr - RR : rr;
-                    const f2* p = ring2 + rr * PITCH + OW + hu_c;
-                    const f2 a = p[0], b = p[1];
-                    hov = (f4){a.x, a.y, b.x, b.y};
+                    const float* p = ring2 + rr * ROWF + OW + hu_c;
+                    const f2 a = *(const f2*)p, b = *(const f2*)(p + OFF1);
+                    hov = (f4){a.x, b.x, a.y, b.y};
                 }
                 st16_sc1(r_out, (unsigned)((i * REC_F2) * 8) + hu_off(), hov);
             }
-            if (i + 1 < NI) issue_guid(i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_guid(i + 1);      // (rows are clamped into the image: harmless behind the last iteration)
             V4_STAMP(7);
             wg_barrier();
             rbp = rb;
@@ -1135,7 +1165,12 @@ static int launch_walk4(const v4::Args& a, hipStream_t st) {
     int dev = 0, ncu = 256;
     SMX_HIP(hipGetDevice(&dev));
     SMX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
-    const int slots = 2 * ncu;                           // persistent: two workgroups per CU
+    int per_cu = v4::WG_PER_CU;                          // persistent: WG_PER_CU workgroups per CU
+    if (const char* e = getenv("SMX_V4_WG_PER_CU")) {    // experiments: fewer workgroups per CU
+        const int v = atoi(e);
+        if (v >= 1 && v <= v4::WG_PER_CU) per_cu = v;
+    }
+    const int slots = per_cu * ncu;
     const int grid = a.nitems < slots ? a.nitems : slots;
     if (a.R == v4::RMAX)
         hipLaunchKernelGGL((v4::k_v4_walk<SRC, v4::RMAX>), dim3((unsigned)grid), dim3(v4::NT), 0, st, a);
@@ -1154,7 +1189,7 @@ extern "C" __attribute__((visibility("default"))) int smx_debug_read_itemlog(uns
 #endif
 #ifdef SMX_V4_DUMP
 extern "C" __attribute__((visibility("default"))) int smx_debug_read_dump(float* out, int n) {
-    const int m = 2 * 2 * v4::RR * v4::PITCH;
+    const int m = 2 * v4::RR * v4::ROWF;
     SMX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(v4::g_dump), sizeof(float) * (n < m ? n : m)));
     return m;
 }

@@ -14,7 +14,10 @@ static thread_local bool g_timing = false;
 static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 static thread_local bool g_ev_valid = false;
 static thread_local int g_launches = 0;
-static int g_agg_path = 0;                 // 0 auto, 1 force multi-kernel, 2 force fused, 3 force the round-2 fused kernel
+#ifndef SMX_DEFAULT_AGG_PATH
+#define SMX_DEFAULT_AGG_PATH 0
+#endif
+static int g_agg_path = SMX_DEFAULT_AGG_PATH;   // 0 auto, 1 force multi-kernel, 2 force fused, 3 force the round-2 fused kernel
 static thread_local int g_last_path = 0;
 
 // smx_agg_v3.hip

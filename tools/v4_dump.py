@@ -12,15 +12,16 @@ import stereo_matching_cuda_amd as smx
 from stereo_matching_cuda_amd import synth
 from stereo_matching_cuda_amd.device import PairPipeline
 w, h, D, item, it, ph = [int(a) for a in sys.argv[1:7]]
-R, RR, PITCH, BH, OW = 9, 52, 85, 32, 64
+BH = int(os.environ.get('SMX_V4_BH', '16'))
+R, RR, ROWF, OFF1, OW = 9, BH + 20, 172, 88, 64
 Il, Ir = synth.gen_pair(w, h, D, 1)
 pipe = PairPipeline(w, h, D)
 pipe.run(torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda())
 torch.cuda.synchronize()
 L = C.CDLL(os.environ["SMX_LIB_PATH"])
-buf = np.zeros(2 * 2 * RR * PITCH, np.float32)
+buf = np.zeros(2 * RR * ROWF, np.float32)
 L.smx_debug_read_dump(buf.ctypes.data_as(C.c_void_p), buf.size)
-rings = buf.reshape(2, RR, PITCH, 2)
+rings = buf.reshape(2, RR, ROWF)
 K = (w + R + OW - 1) // OW
 nsv = 2 * D
 k, sv = divmod(item, nsv)
@@ -42,7 +43,8 @@ def cmp(name, exp, ring, rows, y_of, cols, x_of):
         for j in cols:
             x = x_of(j)
             if x < 0 or x >= w: continue
-            got = rings[ring, (y + (R if ring == 1 else 0)) % RR, j]
+            rr_ = rings[ring, (y + (R if ring == 1 else 0)) % RR]
+            got = np.array([rr_[j], rr_[OFF1 + j]], np.float32)
             e = np.array([exp[0][y, x], exp[1][y, x]], np.float32)
             if got.view(np.uint32).tolist() != e.view(np.uint32).tolist():
                 if bad < 6: print(f"  {name} mismatch y={y} x={x} (ring col {j}): got {got} want {e}")

@@ -35,4 +35,4 @@ for it in range(nit):
         a = r[wv]
         print(f"   w{wv}: W {a[1]-a[0]:5d} (+wait {a[2]-a[1]:5d})  R {a[3]-a[2]:5d} (+{a[4]-a[3]:5d})  "
               f"C {a[5]-a[4]:5d} (+{a[6]-a[5]:5d})  X {a[7]-a[6]:5d} (+{int(nxt[wv]-a[7]):5d})"
-              f"   X: out {a[8]-a[6]:5d} box2 {a[9]-a[8]:5d} box1 {a[10]-a[9]:5d} next {a[7]-a[10]:5d}")
+              f"   X: out {a[8]-a[6]:5d} box1 {a[9]-a[8]:5d} box2 {a[10]-a[9]:5d} next {a[7]-a[10]:5d}  R: carry {a[11]-a[2] if a[11] else 0:5d}")
