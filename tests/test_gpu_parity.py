@@ -333,7 +333,7 @@ def _ragged_shapes():
     w + R crossing a strip count), heights around multiples of the band height BH (exact multi-band
     heights, one row more / less, heights whose lagged stage-2 / q rows need an extra band)."""
     # literal copies of the library constants; test_ragged_shapes_match_the_library_geometry pins them
-    OW, BH = 64, 26
+    OW, BH = 64, 16
     ws = [2, OW - 1, OW, OW + 1, 2 * OW - 9, 2 * OW - 8, 2 * OW, 2 * OW + 1, 3 * OW - 1]
     hs = [1, BH - 1, BH, BH + 1, 2 * BH, 2 * BH + 1, 3 * BH - 18, 3 * BH - 9, 3 * BH, 4 * BH + 7]
     shapes = [(2, 1, 2), (20, 20, 3), (19, 40, 4), (300, 200, 70)]
@@ -345,14 +345,14 @@ def _ragged_shapes():
 
 
 def test_ragged_shapes_match_the_library_geometry():
-    assert _geometry(9) == (64, 26, 83)
-    assert _geometry(0) == (64, 26, 65)
+    assert _geometry(9) == (64, 16, 83)
+    assert _geometry(0) == (64, 16, 65)
 
 
 @pytest.mark.parametrize("w,h,D", _ragged_shapes())
 def test_fused_path_small_and_ragged(orc, w, h, D):
-    """Strip / band / ring boundaries of the fused kernel (64 output columns per strip, 26-row bands,
-    78-row rings at the time of writing -- the shapes follow smx_agg_geometry), images smaller than
+    """Strip / band / ring boundaries of the fused kernel (64 output columns per strip, 16-row bands,
+    36-row rings at the time of writing -- the shapes follow smx_agg_geometry), images smaller than
     one tile, disparity ranges wider than the image."""
     rng = np.random.default_rng(w * 7 + h * 3 + D)
     base = rng.integers(0, 256, size=(h, w + D), dtype=np.uint8)
@@ -364,7 +364,7 @@ def test_fused_path_small_and_ragged(orc, w, h, D):
         _eq(r[k], want[k], k)
 
 
-@pytest.mark.parametrize("radius,w,h", [(0, 128, 52), (0, 129, 53), (4, 64, 26), (4, 65, 78), (4, 192, 27)])
+@pytest.mark.parametrize("radius,w,h", [(0, 128, 52), (0, 129, 53), (4, 64, 26), (4, 65, 78), (4, 192, 27), (4, 64, 16), (9, 130, 33), (1, 70, 48)])
 def test_fused_path_small_radius_at_tile_edges(orc, radius, w, h):
     """Radii other than 9 change the tile width (OW + 2R + 1), the halo width and the row lags."""
     D = 5
