@@ -122,6 +122,18 @@ typedef struct smx_pair_out {
 int smx_stereo_pair(const smx_params* p, const uint8_t* gray_l, const uint8_t* gray_r, int w,
                     int h, int size_d, int dminl, int dminr, const smx_pair_out* out);
 
+/* Persistent context for the host-pointer pair entry: device buffers, workspace and stream are created once
+ * and reused by every pair of the same shape.  It replaces the per-call allocation churn of the reference's
+ * wrappers (guidedFilter.cu:50-56,182-194: 13 planes uploaded per slice; integral.cu:3-51: five cudaMalloc /
+ * cudaFree per call), which smx_stereo_pair still pays once per call (it is smx_create + smx_ctx_stereo_pair +
+ * smx_destroy).  The context belongs to the device that was current at smx_create; use it from one host thread
+ * at a time.  cost_* / agg_* volumes are allocated on first request and kept. */
+typedef struct smx_ctx smx_ctx;
+int smx_create(const smx_params* p, int w, int h, int size_d, smx_ctx** ctx);
+int smx_ctx_stereo_pair(smx_ctx* ctx, const uint8_t* gray_l, const uint8_t* gray_r, int dminl, int dminr,
+                        const smx_pair_out* out);
+int smx_destroy(smx_ctx* ctx);
+
 /* ------------------------------------------------------------------------------------
  * Device-pointer API (async on `stream`, no allocation inside)
  * ---------------------------------------------------------------------------------- */

@@ -22,11 +22,32 @@ extern "C" {
  * nccl_comm: an ncclComm_t (as void*) whose rank lives on the current device. */
 int smx_wta_allreduce(int64_t* d_keys, int64_t n, void* nccl_comm, void* stream);
 
-/* main.cu:65-155 for one pair with the slices [0, size_d) of both volumes sharded over the first
- * `ngpu` devices of this node, driven from ONE host thread (ncclCommInitAll; grouped all-reduce).
- * Device g aggregates slices [g*size_d/ngpu, (g+1)*size_d/ngpu); images are replicated, guidance
- * statistics recomputed per device (deterministic, bit-equal).  Decode + LR check + fill run on
- * device 0.  Host pointers in/out like smx_stereo_pair; cost_* / agg_* outputs must be NULL. */
+/* The same as a MIN reduce to rank `root` only: the LR check and the filling run on one rank
+ * (SURVEY 8e), so the other ranks need not receive the reassembled maps. */
+int smx_wta_reduce(int64_t* d_keys, int64_t n, int root, void* nccl_comm, void* stream);
+
+/* Persistent sharded context: main.cu:65-155 for pairs of one shape with the slices [0, size_d) of both
+ * volumes sharded over the first `ngpu` devices of this node, driven from ONE host thread.  Created once:
+ * the RCCL communicator (ncclCommInitAll), two streams and three events per device, image / key / mean
+ * buffers and the aggregation workspace of every device, the decode buffers of device 0.  A pair is then
+ * only: upload, aggregate (device g: slices [g*size_d/ngpu, (g+1)*size_d/ngpu); images replicated, guidance
+ * statistics recomputed per device: deterministic, bit-equal), ONE exchange step (grouped ncclReduce to
+ * device 0 of the 2*n packed keys), decode + LR check + fill on device 0, download.
+ * flags: SMX_SHARDED_OVERLAP_VIEWS = one aggregation launch per view, the exchange of the left keys runs on
+ *        a second stream under the aggregation of the right volume (pays when the exchange is a visible
+ *        part of a pair; costs a second, smaller launch per device);
+ *        SMX_SHARDED_ALLREDUCE = all-reduce instead of reduce (every rank ends with the reassembled keys).
+ * Host pointers in/out like smx_stereo_pair; cost_* / agg_* outputs must be NULL. */
+#define SMX_SHARDED_OVERLAP_VIEWS 1
+#define SMX_SHARDED_ALLREDUCE 2
+typedef struct smx_sharded_ctx smx_sharded_ctx;
+int smx_sharded_create(const smx_params* p, int w, int h, int size_d, int ngpu, int flags, smx_sharded_ctx** ctx);
+int smx_sharded_run(smx_sharded_ctx* ctx, const uint8_t* gray_l, const uint8_t* gray_r, int dminl, int dminr,
+                    const smx_pair_out* out);
+int smx_sharded_destroy(smx_sharded_ctx* ctx);
+
+/* One pair on a temporary context (smx_sharded_create + smx_sharded_run + smx_sharded_destroy): pays the
+ * communicator set-up and every allocation per call.  Kept for the reference-style one-shot driver. */
 int smx_stereo_pair_sharded(const smx_params* p, const uint8_t* gray_l, const uint8_t* gray_r, int w,
                             int h, int size_d, int dminl, int dminr, int ngpu, const smx_pair_out* out);
 

@@ -2,6 +2,7 @@
 // orchestration, and the host-pointer wrappers that mirror the reference's per-stage functions.
 #include <string.h>
 
+#include <new>
 #include <string>
 #include <vector>
 
@@ -526,84 +527,132 @@ int smx_filter(const smx_params* p, const uint8_t* image, int w, int h, uint8_t*
     return SMX_OK;
 }
 
-int smx_stereo_pair(const smx_params* p, const uint8_t* gray_l, const uint8_t* gray_r, int w, int h,
-                    int size_d, int dminl, int dminr, const smx_pair_out* out) {
-    SMX_ARG(p && gray_l && gray_r && out && w >= 2 && h >= 1 && size_d >= 1);
-    const size_t n = (size_t)w * h;
-    const size_t fb = n * sizeof(float);
-    const size_t vb = fb * size_d;
-    const size_t ws_bytes = 2 * pick_ws_bytes(w, h, size_d);     // both views per launch
+// ---- persistent context of the host-pointer pair entry ---------------------------------------------
+struct smx_ctx {
+    smx_params p;
+    int w = 0, h = 0, size_d = 0, dev = -1;
+    size_t n = 0, ws_bytes = 0;
+    hipStream_t st = nullptr;
     // keys / best / dmap / mean: left view first, right view behind it (one buffer each)
-    DevBuf dL, dR, keys, best, map, mean, occ, fil, ws;
-    DevBuf costL, costR, aggLR;
-    SMX_HIP(dL.alloc(n)); SMX_HIP(dR.alloc(n));
-    SMX_HIP(keys.alloc(2 * n * 8));
-    SMX_HIP(best.alloc(2 * fb)); SMX_HIP(map.alloc(2 * fb));
-    SMX_HIP(mean.alloc(2 * n));
-    SMX_HIP(occ.alloc(fb)); SMX_HIP(fil.alloc(fb));
-    SMX_HIP(ws.alloc(ws_bytes));
+    DevBuf dL, dR, keys, best, map, mean, occ, fil, ws, costL, costR, aggLR;
+    ~smx_ctx() {
+        if (st) (void)hipStreamDestroy(st);
+    }
+};
+
+int smx_create(const smx_params* p, int w, int h, int size_d, smx_ctx** out) {
+    SMX_ARG(p && out && w >= 2 && h >= 1 && size_d >= 1 && p->radius >= 0);
+    *out = nullptr;
+    smx_ctx* c = new (std::nothrow) smx_ctx;
+    if (!c) return fail(SMX_E_HIP, "smx_create: out of host memory");
+    struct Guard { smx_ctx* c; ~Guard() { delete c; } } guard{c};
+    c->p = *p; c->w = w; c->h = h; c->size_d = size_d;
+    c->n = (size_t)w * h;
+    const size_t n = c->n, fb = n * sizeof(float);
+    SMX_HIP(hipGetDevice(&c->dev));
+    SMX_HIP(hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking));
+    c->ws_bytes = 2 * pick_ws_bytes(w, h, size_d);     // both views per launch
+    SMX_HIP(c->dL.alloc(n)); SMX_HIP(c->dR.alloc(n));
+    SMX_HIP(c->keys.alloc(2 * n * 8));
+    SMX_HIP(c->best.alloc(2 * fb)); SMX_HIP(c->map.alloc(2 * fb));
+    SMX_HIP(c->mean.alloc(2 * n));
+    SMX_HIP(c->occ.alloc(fb)); SMX_HIP(c->fil.alloc(fb));
+    SMX_HIP(c->ws.alloc(c->ws_bytes));
+    guard.c = nullptr;
+    *out = c;
+    return SMX_OK;
+}
+
+int smx_destroy(smx_ctx* c) {
+    if (!c) return SMX_OK;
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    if (c->dev >= 0 && dev != c->dev) (void)hipSetDevice(c->dev);
+    if (c->st) (void)hipStreamSynchronize(c->st);
+    delete c;
+    if (dev >= 0) (void)hipSetDevice(dev);
+    return SMX_OK;
+}
+
+int smx_ctx_stereo_pair(smx_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r, int dminl, int dminr,
+                        const smx_pair_out* out) {
+    SMX_ARG(c && gray_l && gray_r && out);
+    const smx_params* p = &c->p;
+    const int w = c->w, h = c->h, size_d = c->size_d;
+    const size_t n = c->n, fb = n * sizeof(float), vb = fb * size_d;
+    int dev = -1;
+    SMX_HIP(hipGetDevice(&dev));
+    if (dev != c->dev) return fail(SMX_E_ARG, "smx_ctx_stereo_pair: the context lives on device %d, current device is %d", c->dev, dev);
+    hipStream_t st = c->st;
     const bool want_cost = out->cost_l || out->cost_r;
     const bool want_agg = out->agg_l || out->agg_r;
-    if (want_cost) { SMX_HIP(costL.alloc(vb)); SMX_HIP(costR.alloc(vb)); }
-    if (want_agg) SMX_HIP(aggLR.alloc(2 * vb));
-    SMX_HIP(hipMemcpy(dL.p, gray_l, n, hipMemcpyHostToDevice));
-    SMX_HIP(hipMemcpy(dR.p, gray_r, n, hipMemcpyHostToDevice));
+    if (want_cost && !c->costL.p) { SMX_HIP(c->costL.alloc(vb)); SMX_HIP(c->costR.alloc(vb)); }
+    if (want_agg && !c->aggLR.p) SMX_HIP(c->aggLR.alloc(2 * vb));
+    uint8_t* dL = c->dL.as<uint8_t>(); uint8_t* dR = c->dR.as<uint8_t>();
+    SMX_HIP(hipMemcpyAsync(dL, gray_l, n, hipMemcpyHostToDevice, st));
+    SMX_HIP(hipMemcpyAsync(dR, gray_r, n, hipMemcpyHostToDevice, st));
     int rc;
     const int64_t nn = (int64_t)n;
-    float* bestL = best.as<float>(); float* bestR = bestL + n;
-    float* mapL = map.as<float>();   float* mapR = mapL + n;
-    int64_t* keysL = keys.as<int64_t>(); int64_t* keysR = keysL + n;
+    float* bestL = c->best.as<float>(); float* bestR = bestL + n;
+    float* mapL = c->map.as<float>();   float* mapR = mapL + n;
+    int64_t* keysL = c->keys.as<int64_t>(); int64_t* keysR = keysL + n;
     // cost volumes are materialised only when the caller asks for them (main.cu:80-82) and then feed
     // the aggregation like in the reference; otherwise the slices are built on the fly inside it.
     if (want_cost) {
-        if ((rc = smx_dev_cost_volume(p, dL.as<uint8_t>(), dR.as<uint8_t>(), costL.as<float>(), w, w, h,
-                                      dminl, 0, size_d, nullptr))) return rc;
-        if ((rc = smx_dev_cost_volume(p, dR.as<uint8_t>(), dL.as<uint8_t>(), costR.as<float>(), w, w, h,
-                                      dminr, 0, size_d, nullptr))) return rc;
+        if ((rc = smx_dev_cost_volume(p, dL, dR, c->costL.as<float>(), w, w, h, dminl, 0, size_d, st))) return rc;
+        if ((rc = smx_dev_cost_volume(p, dR, dL, c->costR.as<float>(), w, w, h, dminr, 0, size_d, st))) return rc;
     }
-    if ((rc = smx_dev_init_keys(keysL, 2 * nn, nullptr))) return rc;
+    if ((rc = smx_dev_init_keys(keysL, 2 * nn, st))) return rc;
     // main.cu:133-134, both views per kernel launch
     if (v3_supported(p) && g_agg_path != 1) {
-        const uint8_t* guide[2] = {dL.as<uint8_t>(), dR.as<uint8_t>()};
-        const uint8_t* other[2] = {dR.as<uint8_t>(), dL.as<uint8_t>()};
-        const float* cost[2] = {costL.as<float>(), costR.as<float>()};
+        const uint8_t* guide[2] = {dL, dR};
+        const uint8_t* other[2] = {dR, dL};
+        const float* cost[2] = {c->costL.as<float>(), c->costR.as<float>()};
         const int dmin[2] = {dminl, dminr};
         int64_t* kv[2] = {keysL, keysR};
-        uint8_t* mv[2] = {mean.as<uint8_t>(), mean.as<uint8_t>() + n};
-        float* av[2] = {aggLR.as<float>(), want_agg ? aggLR.as<float>() + (size_t)size_d * n : nullptr};
+        uint8_t* mv[2] = {c->mean.as<uint8_t>(), c->mean.as<uint8_t>() + n};
+        float* av[2] = {c->aggLR.as<float>(), want_agg ? c->aggLR.as<float>() + (size_t)size_d * n : nullptr};
         g_launches = 0;
         if ((rc = aggregate_fused(p, 2, guide, other, want_cost ? cost : nullptr, w, h, dmin, 0, size_d, kv, mv,
-                               want_agg ? av : nullptr, ws.p, ws_bytes, nullptr, &g_launches)))
+                                  want_agg ? av : nullptr, c->ws.p, c->ws_bytes, st, &g_launches)))
             return rc;
         g_last_path = g_agg_path == 3 ? 3 : 2;
     } else {
-        if ((rc = smx_dev_aggregate_wta(p, dL.as<uint8_t>(), dR.as<uint8_t>(),
-                                        want_cost ? costL.as<float>() : nullptr, w, h, dminl, 0, size_d, keysL,
-                                        mean.as<uint8_t>(), want_agg ? aggLR.as<float>() : nullptr, ws.p,
-                                        ws_bytes, nullptr)))
+        if ((rc = smx_dev_aggregate_wta(p, dL, dR, want_cost ? c->costL.as<float>() : nullptr, w, h, dminl, 0, size_d,
+                                        keysL, c->mean.as<uint8_t>(), want_agg ? c->aggLR.as<float>() : nullptr, c->ws.p,
+                                        c->ws_bytes, st)))
             return rc;
-        if ((rc = smx_dev_aggregate_wta(p, dR.as<uint8_t>(), dL.as<uint8_t>(),
-                                        want_cost ? costR.as<float>() : nullptr, w, h, dminr, 0, size_d, keysR,
-                                        mean.as<uint8_t>() + n,
-                                        want_agg ? aggLR.as<float>() + (size_t)size_d * n : nullptr, ws.p,
-                                        ws_bytes, nullptr)))
+        if ((rc = smx_dev_aggregate_wta(p, dR, dL, want_cost ? c->costR.as<float>() : nullptr, w, h, dminr, 0, size_d,
+                                        keysR, c->mean.as<uint8_t>() + n,
+                                        want_agg ? c->aggLR.as<float>() + (size_t)size_d * n : nullptr, c->ws.p,
+                                        c->ws_bytes, st)))
             return rc;
     }
     // main.cu:112-118 presets, winning slices, main.cu:140-155
     if ((rc = smx_dev_finish_pair(p, keysL, w, h, dminl, dminr, dminl - 100, (float)dminl, bestL, mapL,
-                                  occ.as<float>(), fil.as<float>(), nullptr))) return rc;
-    SMX_HIP(hipDeviceSynchronize());
-    if ((rc = smx_dev_agg_status(ws.p))) return rc;
+                                  c->occ.as<float>(), c->fil.as<float>(), st))) return rc;
     struct { void* dst; const void* src; size_t b; } copies[] = {
         {out->best_l, bestL, fb}, {out->best_r, bestR, fb}, {out->dmap_l, mapL, fb},
-        {out->dmap_r, mapR, fb},  {out->mean_l, mean.p, n}, {out->mean_r, mean.as<uint8_t>() + n, n},
-        {out->occlusion, occ.p, fb}, {out->filled, fil.p, fb},  {out->cost_l, costL.p, vb},
-        {out->cost_r, costR.p, vb}, {out->agg_l, aggLR.p, vb},
-        {out->agg_r, want_agg ? (const void*)(aggLR.as<float>() + (size_t)size_d * n) : nullptr, vb},
+        {out->dmap_r, mapR, fb},  {out->mean_l, c->mean.p, n}, {out->mean_r, c->mean.as<uint8_t>() + n, n},
+        {out->occlusion, c->occ.p, fb}, {out->filled, c->fil.p, fb},  {out->cost_l, c->costL.p, vb},
+        {out->cost_r, c->costR.p, vb}, {out->agg_l, c->aggLR.p, vb},
+        {out->agg_r, want_agg ? (const void*)(c->aggLR.as<float>() + (size_t)size_d * n) : nullptr, vb},
     };
-    for (auto& c : copies)
-        if (c.dst && c.src) SMX_HIP(hipMemcpy(c.dst, c.src, c.b, hipMemcpyDeviceToHost));
-    return SMX_OK;
+    for (auto& cp : copies)
+        if (cp.dst && cp.src) SMX_HIP(hipMemcpyAsync(cp.dst, cp.src, cp.b, hipMemcpyDeviceToHost, st));
+    SMX_HIP(hipStreamSynchronize(st));
+    return smx_dev_agg_status(c->ws.p);
+}
+
+int smx_stereo_pair(const smx_params* p, const uint8_t* gray_l, const uint8_t* gray_r, int w, int h,
+                    int size_d, int dminl, int dminr, const smx_pair_out* out) {
+    SMX_ARG(p && gray_l && gray_r && out && w >= 2 && h >= 1 && size_d >= 1);
+    smx_ctx* c = nullptr;
+    int rc = smx_create(p, w, h, size_d, &c);
+    if (rc) return rc;
+    rc = smx_ctx_stereo_pair(c, gray_l, gray_r, dminl, dminr, out);
+    (void)smx_destroy(c);
+    return rc;
 }
 
 }  // extern "C"

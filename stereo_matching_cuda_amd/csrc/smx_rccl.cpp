@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <new>
 #include <vector>
 
 #include "smx_rccl.h"
@@ -36,26 +37,59 @@ int fail(int code, const char* fmt, const char* what, const char* detail, int li
         if (e__ != SMX_OK) return fail(e__, "%s -> %s (line %d)", #call, smx_last_error(), __LINE__);  \
     } while (0)
 
-// everything one device owns for a sharded pair
+// everything one device owns, for the lifetime of the context
 struct Shard {
     int dev = -1;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;       // aggregation
+    hipStream_t cst = nullptr;      // exchange (so that it can overlap the aggregation of the other view)
+    hipEvent_t ev_view[2] = {nullptr, nullptr};   // keys of view v complete on `st`
+    hipEvent_t ev_comm = nullptr;                 // exchange complete on `cst`
     ncclComm_t comm = nullptr;
     uint8_t *L = nullptr, *R = nullptr, *mean = nullptr;
     int64_t* keys = nullptr;
     void* ws = nullptr;
     size_t ws_bytes = 0;
+    int s0 = 0, s1 = 0;             // slice range
     ~Shard() {
         if (dev < 0) return;
         (void)hipSetDevice(dev);
+        if (st) (void)hipStreamSynchronize(st);
+        if (cst) (void)hipStreamSynchronize(cst);
         if (comm) (void)ncclCommDestroy(comm);
         for (void* q : {(void*)L, (void*)R, (void*)mean, (void*)keys, ws})
             if (q) (void)hipFree(q);
+        for (hipEvent_t e : {ev_view[0], ev_view[1], ev_comm})
+            if (e) (void)hipEventDestroy(e);
         if (st) (void)hipStreamDestroy(st);
+        if (cst) (void)hipStreamDestroy(cst);
     }
 };
 
+// a grouped RCCL section that is closed on every path
+struct NcclGroup {
+    bool open = false;
+    ncclResult_t start() { ncclResult_t r = ncclGroupStart(); open = r == ncclSuccess; return r; }
+    ncclResult_t end() { open = false; return ncclGroupEnd(); }
+    ~NcclGroup() { if (open) (void)ncclGroupEnd(); }
+};
+
 }  // namespace
+
+struct smx_sharded_ctx {
+    smx_params p;
+    int w = 0, h = 0, size_d = 0, ngpu = 0, flags = 0;
+    size_t n = 0;
+    std::vector<Shard> sh;
+    // decode + LR check + filling on device 0
+    float *best = nullptr, *map = nullptr, *occ = nullptr, *fil = nullptr;
+    ~smx_sharded_ctx() {
+        if (!sh.empty() && sh[0].dev >= 0) {
+            (void)hipSetDevice(sh[0].dev);
+            for (float* q : {best, map, occ, fil})
+                if (q) (void)hipFree(q);
+        }
+    }
+};
 
 extern "C" {
 
@@ -65,96 +99,165 @@ int smx_wta_allreduce(int64_t* d_keys, int64_t n, void* nccl_comm, void* stream)
     return SMX_OK;
 }
 
-int smx_stereo_pair_sharded(const smx_params* p, const uint8_t* gray_l, const uint8_t* gray_r, int w, int h,
-                            int size_d, int dminl, int dminr, int ngpu, const smx_pair_out* out) {
-    if (!p || !gray_l || !gray_r || !out || w < 2 || h < 1 || size_d < 1 || ngpu < 1)
-        return fail(SMX_E_ARG, "%s: %s (line %d)", "smx_stereo_pair_sharded", "bad argument", __LINE__);
-    if (out->cost_l || out->cost_r || out->agg_l || out->agg_r)
-        return fail(SMX_E_ARG, "%s: %s (line %d)", "smx_stereo_pair_sharded", "cost / agg outputs are not available in the sharded driver", __LINE__);
+int smx_wta_reduce(int64_t* d_keys, int64_t n, int root, void* nccl_comm, void* stream) {
+    if (!d_keys || n <= 0 || !nccl_comm || root < 0) return fail(SMX_E_ARG, "%s: %s (line %d)", "smx_wta_reduce", "bad argument", __LINE__);
+    RC_NCCL(ncclReduce(d_keys, d_keys, (size_t)n, ncclInt64, ncclMin, root, (ncclComm_t)nccl_comm, (hipStream_t)stream));
+    return SMX_OK;
+}
+
+int smx_sharded_create(const smx_params* p, int w, int h, int size_d, int ngpu, int flags, smx_sharded_ctx** out) {
+    if (!p || !out || w < 2 || h < 1 || size_d < 1 || ngpu < 1)
+        return fail(SMX_E_ARG, "%s: %s (line %d)", "smx_sharded_create", "bad argument", __LINE__);
+    *out = nullptr;
     int ndev = 0;
     RC_HIP(hipGetDeviceCount(&ndev));
-    if (ngpu > ndev) return fail(SMX_E_ARG, "%s: %s (line %d)", "smx_stereo_pair_sharded", "more shards than devices", __LINE__);
-    const size_t n = (size_t)w * h;
-    std::vector<Shard> sh(ngpu);
+    if (ngpu > ndev) return fail(SMX_E_ARG, "%s: %s (line %d)", "smx_sharded_create", "more shards than devices", __LINE__);
+    smx_sharded_ctx* c = new (std::nothrow) smx_sharded_ctx;
+    if (!c) return fail(SMX_E_HIP, "%s: %s (line %d)", "smx_sharded_create", "out of host memory", __LINE__);
+    struct Guard { smx_sharded_ctx* c; ~Guard() { delete c; } } guard{c};
+    c->p = *p; c->w = w; c->h = h; c->size_d = size_d; c->ngpu = ngpu; c->flags = flags;
+    c->n = (size_t)w * h;
+    const size_t n = c->n;
+    c->sh.resize(ngpu);
     std::vector<int> devs(ngpu);
-    std::vector<ncclComm_t> comms(ngpu);
+    std::vector<ncclComm_t> comms(ngpu, nullptr);
     for (int g = 0; g < ngpu; ++g) devs[g] = g;
-    RC_NCCL(ncclCommInitAll(comms.data(), ngpu, devs.data()));
-    int max_slices = 0;
-    for (int g = 0; g < ngpu; ++g) {
-        const int s0 = (int)((int64_t)g * size_d / ngpu), s1 = (int)((int64_t)(g + 1) * size_d / ngpu);
-        if (s1 - s0 > max_slices) max_slices = s1 - s0;
+    // the communicators go to their owners before anything else can fail: the Shard destructors release them
+    {
+        ncclResult_t r = ncclCommInitAll(comms.data(), ngpu, devs.data());
+        for (int g = 0; g < ngpu; ++g) { c->sh[g].dev = g; c->sh[g].comm = comms[g]; }
+        if (r != ncclSuccess) return fail(SMX_E_HIP, "%s -> %s (line %d)", "ncclCommInitAll", ncclGetErrorString(r), __LINE__);
     }
-    if (max_slices < 1) max_slices = 1;
+    int max_slices = 1;
+    for (int g = 0; g < ngpu; ++g) {
+        c->sh[g].s0 = (int)((int64_t)g * size_d / ngpu);
+        c->sh[g].s1 = (int)((int64_t)(g + 1) * size_d / ngpu);
+        if (c->sh[g].s1 - c->sh[g].s0 > max_slices) max_slices = c->sh[g].s1 - c->sh[g].s0;
+    }
     // cap the slices in flight at ~4 GiB of workspace per device
     int in_flight = max_slices;
     while (in_flight > 1 && 2 * smx_agg_workspace_bytes(w, h, in_flight) > ((size_t)4 << 30)) in_flight = (in_flight + 1) / 2;
     for (int g = 0; g < ngpu; ++g) {
-        Shard& s = sh[g];
-        s.dev = g;
-        s.comm = comms[g];
+        Shard& s = c->sh[g];
         RC_HIP(hipSetDevice(g));
         RC_HIP(hipStreamCreateWithFlags(&s.st, hipStreamNonBlocking));
+        RC_HIP(hipStreamCreateWithFlags(&s.cst, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&s.ev_view[0], &s.ev_view[1], &s.ev_comm}) RC_HIP(hipEventCreateWithFlags(e, hipEventDisableTiming));
         s.ws_bytes = 2 * smx_agg_workspace_bytes(w, h, in_flight);
         RC_HIP(hipMalloc((void**)&s.L, n));
         RC_HIP(hipMalloc((void**)&s.R, n));
         RC_HIP(hipMalloc((void**)&s.mean, 2 * n));
         RC_HIP(hipMalloc((void**)&s.keys, 2 * n * sizeof(int64_t)));
         RC_HIP(hipMalloc(&s.ws, s.ws_bytes));
+    }
+    RC_HIP(hipSetDevice(0));
+    const size_t fb = n * sizeof(float);
+    RC_HIP(hipMalloc((void**)&c->best, 2 * fb));
+    RC_HIP(hipMalloc((void**)&c->map, 2 * fb));
+    RC_HIP(hipMalloc((void**)&c->occ, fb));
+    RC_HIP(hipMalloc((void**)&c->fil, fb));
+    guard.c = nullptr;
+    *out = c;
+    return SMX_OK;
+}
+
+int smx_sharded_destroy(smx_sharded_ctx* c) {
+    if (!c) return SMX_OK;
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    delete c;
+    if (dev >= 0) (void)hipSetDevice(dev);
+    return SMX_OK;
+}
+
+int smx_sharded_run(smx_sharded_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r, int dminl, int dminr,
+                    const smx_pair_out* out) {
+    if (!c || !gray_l || !gray_r || !out)
+        return fail(SMX_E_ARG, "%s: %s (line %d)", "smx_sharded_run", "bad argument", __LINE__);
+    if (out->cost_l || out->cost_r || out->agg_l || out->agg_r)
+        return fail(SMX_E_ARG, "%s: %s (line %d)", "smx_sharded_run", "cost / agg outputs are not available in the sharded driver", __LINE__);
+    const smx_params* p = &c->p;
+    const int w = c->w, h = c->h, ngpu = c->ngpu;
+    const size_t n = c->n;
+    const bool per_view = (c->flags & SMX_SHARDED_OVERLAP_VIEWS) != 0;
+    const bool all_ranks = (c->flags & SMX_SHARDED_ALLREDUCE) != 0;
+    // upload + local aggregation + running WTA of every device's slice range (asynchronous, all devices busy)
+    for (int g = 0; g < ngpu; ++g) {
+        Shard& s = c->sh[g];
+        RC_HIP(hipSetDevice(g));
         RC_HIP(hipMemcpyAsync(s.L, gray_l, n, hipMemcpyHostToDevice, s.st));
         RC_HIP(hipMemcpyAsync(s.R, gray_r, n, hipMemcpyHostToDevice, s.st));
-    }
-    // local aggregation + running WTA of every device's slice range (asynchronous, all devices busy)
-    for (int g = 0; g < ngpu; ++g) {
-        Shard& s = sh[g];
-        const int s0 = (int)((int64_t)g * size_d / ngpu), s1 = (int)((int64_t)(g + 1) * size_d / ngpu);
-        RC_HIP(hipSetDevice(g));
         RC_SMX(smx_dev_init_keys(s.keys, (int64_t)(2 * n), s.st));
-        RC_SMX(smx_dev_aggregate_wta_pair(p, s.L, s.R, w, h, dminl, dminr, s0, s1, s.keys, s.mean, nullptr, s.ws,
-                                          s.ws_bytes, s.st));
+        if (per_view) {
+            // one launch per view: the exchange of the left keys runs under the aggregation of the right volume
+            RC_SMX(smx_dev_aggregate_wta(p, s.L, s.R, nullptr, w, h, dminl, s.s0, s.s1, s.keys, s.mean, nullptr, s.ws,
+                                         s.ws_bytes, s.st));
+            RC_HIP(hipEventRecord(s.ev_view[0], s.st));
+            RC_SMX(smx_dev_aggregate_wta(p, s.R, s.L, nullptr, w, h, dminr, s.s0, s.s1, s.keys + n, s.mean + n, nullptr, s.ws,
+                                         s.ws_bytes, s.st));
+            RC_HIP(hipEventRecord(s.ev_view[1], s.st));
+        } else {
+            RC_SMX(smx_dev_aggregate_wta_pair(p, s.L, s.R, w, h, dminl, dminr, s.s0, s.s1, s.keys, s.mean, nullptr, s.ws,
+                                              s.ws_bytes, s.st));
+            RC_HIP(hipEventRecord(s.ev_view[1], s.st));
+        }
     }
-    // the one exchange step: grouped because one thread drives all ranks
-    RC_NCCL(ncclGroupStart());
+    // the one exchange step, on the exchange streams; grouped because one thread drives all ranks.  Only
+    // device 0 needs the reassembled maps (ncclReduce) unless the caller asked for them on every rank.
+    const int nex = per_view ? 2 : 1;
+    for (int x = 0; x < nex; ++x) {
+        int64_t* off = nullptr;
+        const int64_t cnt = per_view ? (int64_t)n : (int64_t)(2 * n);
+        for (int g = 0; g < ngpu; ++g) {
+            RC_HIP(hipSetDevice(g));
+            RC_HIP(hipStreamWaitEvent(c->sh[g].cst, c->sh[g].ev_view[per_view ? x : 1], 0));
+        }
+        NcclGroup grp;
+        RC_NCCL(grp.start());
+        for (int g = 0; g < ngpu; ++g) {
+            Shard& s = c->sh[g];
+            RC_HIP(hipSetDevice(g));
+            off = s.keys + (per_view ? (size_t)x * n : 0);
+            if (all_ranks) RC_SMX(smx_wta_allreduce(off, cnt, s.comm, s.cst));
+            else RC_SMX(smx_wta_reduce(off, cnt, 0, s.comm, s.cst));
+        }
+        RC_NCCL(grp.end());
+    }
     for (int g = 0; g < ngpu; ++g) {
         RC_HIP(hipSetDevice(g));
-        RC_SMX(smx_wta_allreduce(sh[g].keys, (int64_t)(2 * n), sh[g].comm, sh[g].st));
+        RC_HIP(hipEventRecord(c->sh[g].ev_comm, c->sh[g].cst));
     }
-    RC_NCCL(ncclGroupEnd());
-    // decode + LR check + filling on device 0 (n-sized, microseconds)
+    // decode + LR check + filling on device 0 (n-sized, microseconds): main.cu:112-118, 140-155
     RC_HIP(hipSetDevice(0));
-    hipStream_t st = sh[0].st;
-    float *best = nullptr, *map = nullptr, *occ = nullptr, *fil = nullptr;
+    hipStream_t st = c->sh[0].st;
+    RC_HIP(hipStreamWaitEvent(st, c->sh[0].ev_comm, 0));
+    RC_SMX(smx_dev_finish_pair(p, c->sh[0].keys, w, h, dminl, dminr, dminl - 100, (float)dminl, c->best, c->map, c->occ,
+                               c->fil, st));
     const size_t fb = n * sizeof(float);
-    RC_HIP(hipMalloc((void**)&best, 2 * fb));
-    RC_HIP(hipMalloc((void**)&map, 2 * fb));
-    RC_HIP(hipMalloc((void**)&occ, fb));
-    RC_HIP(hipMalloc((void**)&fil, fb));
-    int rc = SMX_OK;
-    do {
-        if ((rc = smx_dev_init_wta(best, map, (int64_t)(2 * n), st))) break;
-        if ((rc = smx_dev_apply_keys(sh[0].keys, (int64_t)n, dminl, best, map, st))) break;
-        if ((rc = smx_dev_apply_keys(sh[0].keys + n, (int64_t)n, dminr, best + n, map + n, st))) break;
-        if (hipMemcpyAsync(occ, map, fb, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = SMX_E_HIP; break; }
-        if ((rc = smx_dev_detect_occlusion(p, occ, map + n, dminl - 100, w, h, st))) break;      // main.cu:149
-        if (hipMemcpyAsync(fil, occ, fb, hipMemcpyDeviceToDevice, st) != hipSuccess) { rc = SMX_E_HIP; break; }
-        if ((rc = smx_dev_fill_occlusion(fil, w, h, (float)dminl, st))) break;                   // main.cu:154
-        for (int g = 0; g < ngpu && rc == SMX_OK; ++g) {
-            if (hipSetDevice(g) != hipSuccess || hipStreamSynchronize(sh[g].st) != hipSuccess) { rc = SMX_E_HIP; break; }
-            rc = smx_dev_agg_status(sh[g].ws);
-        }
-        if (rc) break;
-        (void)hipSetDevice(0);
-        struct { void* dst; const void* src; size_t b; } copies[] = {
-            {out->best_l, best, fb}, {out->best_r, best + n, fb}, {out->dmap_l, map, fb}, {out->dmap_r, map + n, fb},
-            {out->mean_l, sh[0].mean, n}, {out->mean_r, sh[0].mean + n, n}, {out->occlusion, occ, fb}, {out->filled, fil, fb},
-        };
-        for (auto& c : copies)
-            if (c.dst && hipMemcpy(c.dst, c.src, c.b, hipMemcpyDeviceToHost) != hipSuccess) { rc = SMX_E_HIP; break; }
-    } while (0);
-    (void)hipSetDevice(0);
-    for (float* q : {best, map, occ, fil}) (void)hipFree(q);
-    if (rc) return fail(rc, "%s: %s (line %d)", "smx_stereo_pair_sharded", smx_last_error(), __LINE__);
+    struct { void* dst; const void* src; size_t b; } copies[] = {
+        {out->best_l, c->best, fb}, {out->best_r, c->best + n, fb}, {out->dmap_l, c->map, fb}, {out->dmap_r, c->map + n, fb},
+        {out->mean_l, c->sh[0].mean, n}, {out->mean_r, c->sh[0].mean + n, n}, {out->occlusion, c->occ, fb}, {out->filled, c->fil, fb},
+    };
+    for (auto& cp : copies)
+        if (cp.dst) RC_HIP(hipMemcpyAsync(cp.dst, cp.src, cp.b, hipMemcpyDeviceToHost, st));
+    for (int g = 0; g < ngpu; ++g) {
+        RC_HIP(hipSetDevice(g));
+        RC_HIP(hipStreamSynchronize(c->sh[g].cst));
+        RC_HIP(hipStreamSynchronize(c->sh[g].st));
+        RC_SMX(smx_dev_agg_status(c->sh[g].ws));
+    }
+    RC_HIP(hipSetDevice(0));
     return SMX_OK;
+}
+
+int smx_stereo_pair_sharded(const smx_params* p, const uint8_t* gray_l, const uint8_t* gray_r, int w, int h,
+                            int size_d, int dminl, int dminr, int ngpu, const smx_pair_out* out) {
+    smx_sharded_ctx* c = nullptr;
+    int rc = smx_sharded_create(p, w, h, size_d, ngpu, 0, &c);
+    if (rc) return rc;
+    rc = smx_sharded_run(c, gray_l, gray_r, dminl, dminr, out);
+    (void)smx_sharded_destroy(c);
+    return rc;
 }
 
 }  // extern "C"

@@ -16,10 +16,17 @@
 //   --pfm FILE        filled left disparity (positive pixels) as a Middlebury-style PFM
 //   --png16 FILE      filled left disparity as a KITTI-style 16-bit PNG (disparity * 256)
 //   --ngpu N          disparity-shard the aggregation over N GPUs of this node: every GPU aggregates
-//                     its slice range, ONE RCCL MIN all-reduce of the packed keys reassembles the map
-//                     (smx_stereo_pair_sharded in libsmx_rccl.so, loaded on demand; implies --fused)
+//                     its slice range, ONE RCCL MIN reduce of the packed keys reassembles the map on GPU 0
+//                     (the persistent context smx_sharded_create / _run / _destroy of libsmx_rccl.so,
+//                     loaded on demand; implies --fused)
+//   --overlap         with --ngpu: one aggregation launch per view, the exchange of the left keys runs
+//                     under the aggregation of the right volume
+//   --pairs K         with --fused / --ngpu: process the pair K times on ONE persistent context (device
+//                     buffers, workspace, streams, communicator created once) and print the time per
+//                     pair, uploads and downloads included
 #include <dlfcn.h>
 
+#include <chrono>
 #include <vector>
 
 #include "costVolume.cuh"
@@ -71,6 +78,8 @@ struct Options {
     bool fused = false, host_compare = false;
     std::string pfm, png16;
     int ngpu = 0;            // 0 = not given: the single-GPU paths
+    int pairs = 1;
+    bool overlap = false;
     bool ok = true;
 };
 
@@ -87,6 +96,8 @@ Options parse(int argc, char** argv) {
         else if (a == "--pfm") value(o.pfm);
         else if (a == "--png16") value(o.png16);
         else if (a == "--ngpu") { std::string v; value(v); o.ngpu = std::atoi(v.c_str()); }
+        else if (a == "--pairs") { std::string v; value(v); o.pairs = std::atoi(v.c_str()); }
+        else if (a == "--overlap") o.overlap = true;
         else if (a.rfind("--", 0) == 0) { std::fprintf(stderr, "unknown option %s\n", a.c_str()); o.ok = false; }
         else o.positional.push_back(a);
     }
@@ -121,18 +132,27 @@ int main(int argc, char** argv) {
         return 2;
     }
     // the multi-GPU driver (RCCL) is loaded only when asked for, so the plain binary does not need librccl
-    typedef int (*sharded_fn)(const smx_params*, const uint8_t*, const uint8_t*, int, int, int, int, int, int,
-                              const smx_pair_out*);
-    sharded_fn pair_sharded = nullptr;
+    typedef int (*sh_create_fn)(const smx_params*, int, int, int, int, int, void**);
+    typedef int (*sh_run_fn)(void*, const uint8_t*, const uint8_t*, int, int, const smx_pair_out*);
+    typedef int (*sh_destroy_fn)(void*);
+    sh_create_fn sh_create = nullptr;
+    sh_run_fn sh_run = nullptr;
+    sh_destroy_fn sh_destroy = nullptr;
     if (opt.ngpu >= 1) {
         void* so = dlopen("libsmx_rccl.so", RTLD_NOW | RTLD_LOCAL);
-        pair_sharded = so ? (sharded_fn)dlsym(so, "smx_stereo_pair_sharded") : nullptr;
-        if (!pair_sharded) {
-            std::fprintf(stderr, "--ngpu: cannot load smx_stereo_pair_sharded from libsmx_rccl.so (%s)\n", dlerror());
+        sh_create = so ? (sh_create_fn)dlsym(so, "smx_sharded_create") : nullptr;
+        sh_run = so ? (sh_run_fn)dlsym(so, "smx_sharded_run") : nullptr;
+        sh_destroy = so ? (sh_destroy_fn)dlsym(so, "smx_sharded_destroy") : nullptr;
+        if (!sh_create || !sh_run || !sh_destroy) {
+            std::fprintf(stderr, "--ngpu: cannot load the sharded context of libsmx_rccl.so (%s)\n", dlerror());
             return 1;
         }
     }
-    const bool fused = opt.fused || pair_sharded;
+    const bool fused = opt.fused || sh_create;
+    if (opt.pairs < 1 || (opt.pairs > 1 && !fused)) {
+        std::fprintf(stderr, "--pairs needs a count >= 1 and --fused or --ngpu\n");
+        return 2;
+    }
 
     const std::clock_t t_begin = std::clock();
     Pair in;
@@ -195,10 +215,25 @@ int main(int argc, char** argv) {
         out.dmap_l = dmap[0].data(); out.dmap_r = dmap[1].data();
         out.mean_l = mean[0].data(); out.mean_r = mean[1].data();
         out.occlusion = occlusion.data(); out.filled = filled.data();
-        if (pair_sharded)
-            CHECK(pair_sharded(&smx_config().params, gray[0], gray[1], w, h, size_d, dmin[0], dmin[1], opt.ngpu, &out));
-        else
-            CHECK(smx_stereo_pair(&smx_config().params, gray[0], gray[1], w, h, size_d, dmin[0], dmin[1], &out));
+        // one persistent context for all pairs: nothing is allocated, created or destroyed per pair
+        void* sctx = nullptr;
+        smx_ctx* ctx = nullptr;
+        if (sh_create) CHECK(sh_create(&smx_config().params, w, h, size_d, opt.ngpu, opt.overlap ? 1 : 0, &sctx));
+        else CHECK(smx_create(&smx_config().params, w, h, size_d, &ctx));
+        auto run_pair = [&]() {
+            return sh_create ? sh_run(sctx, gray[0], gray[1], dmin[0], dmin[1], &out)
+                             : smx_ctx_stereo_pair(ctx, gray[0], gray[1], dmin[0], dmin[1], &out);
+        };
+        CHECK(run_pair());
+        if (opt.pairs > 1) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int k = 1; k < opt.pairs; ++k) CHECK(run_pair());
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            std::printf("pairs %d on one context: %.3f ms per pair, uploads and downloads included\n", opt.pairs - 1,
+                        ms / (opt.pairs - 1));
+        }
+        if (sh_create) CHECK(sh_destroy(sctx));
+        else CHECK(smx_destroy(ctx));
         std::cout << "guided filter ok" << std::endl;
         if (host_compare) {
             std::vector<float> lr(dmap[0]);

@@ -663,3 +663,37 @@ def test_sharded_pair_two_processes_on_one_gpu(orc, tmp_path, world):
         got = np.load(tmp_path / f"rank{rank}.npz")
         for k in KEYS[2:]:
             _eq(got[k], want[k], f"rank{rank} {k}")
+
+
+@pytest.mark.gpu
+def test_persistent_context_reuses_its_buffers(orc):
+    """smx_create / smx_ctx_stereo_pair / smx_destroy (the SURVEY 8b context: device buffers, workspace and
+    stream created once): three different pairs through ONE context, each equal to the oracle bit for bit,
+    and equal to the one-shot smx_stereo_pair."""
+    L = smx.lib()
+    w, h, D = 150, 100, 7
+    params = smx.default_params()
+    ctx = C.c_void_p()
+    smx.check(L.smx_create(C.byref(params), w, h, D, C.byref(ctx)))
+    try:
+        for seed in (11, 12, 13):
+            Il, Ir = synth.gen_pair(w, h, D, seed)
+            want = orc.stereo_pair(Il, Ir, D)
+            n = w * h
+            bufs = {k: np.empty(n, np.float32) for k in ("best_l", "best_r", "dmap_l", "dmap_r", "occlusion", "filled")}
+            means = {k: np.empty(n, np.uint8) for k in ("mean_l", "mean_r")}
+            from stereo_matching_cuda_amd._lib import PairOut
+            out = PairOut()
+            for k, a in {**bufs, **means}.items():
+                setattr(out, k, a.ctypes.data)
+            smx.check(L.smx_ctx_stereo_pair(ctx, Il.ctypes.data, Ir.ctypes.data, -(D - 1), 0, C.byref(out)))
+            for got, key in ((bufs["dmap_l"], "dmapl"), (bufs["dmap_r"], "dmapr"), (bufs["best_l"], "bestl"),
+                             (bufs["best_r"], "bestr"), (bufs["occlusion"], "occlusion"), (bufs["filled"], "filled"),
+                             (means["mean_l"], "meanl"), (means["mean_r"], "meanr")):
+                ref = np.asarray(want[key]).reshape(-1)
+                if got.dtype == np.float32:
+                    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (seed, key)
+                else:
+                    assert np.array_equal(got, ref), (seed, key)
+    finally:
+        smx.check(L.smx_destroy(ctx))

@@ -133,11 +133,14 @@ def _stage_tsukuba(tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags", [["--fused"], ["--host-compare"], ["--fused", "--host-compare"],
-                                   ["--ngpu", "1"]])
+                                   ["--ngpu", "1"], ["--fused", "--pairs", "4"], ["--ngpu", "1", "--pairs", "3"],
+                                   ["--ngpu", "1", "--overlap", "--pairs", "3"]])
 def test_drop_in_main_modes(binary, golden, tmp_path, flags):
     """--fused: one device-resident call after the gray conversion; --host-compare: the reference's
     self-check mode (main.cu:40) with correct CPU twins; --ngpu 1: the RCCL sharded driver of
-    libsmx_rccl.so with a one-rank communicator (the N > 1 call sequence on the one GPU of this box).
+    libsmx_rccl.so with a one-rank communicator (the N > 1 call sequence on the one GPU of this box);
+    --pairs K: K pairs on ONE persistent context (smx_create / smx_sharded_create: nothing allocated per
+    pair); --overlap: one launch per view, the exchange of the left keys on its own stream.
     Same 12 images every way."""
     PIL = pytest.importorskip("PIL.Image")
     data = _stage_tsukuba(tmp_path)
@@ -147,6 +150,8 @@ def test_drop_in_main_modes(binary, golden, tmp_path, flags):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "error at element" not in r.stdout
+    if "--pairs" in flags:
+        assert re.search(r"pairs \d+ on one context: [0-9.]+ ms per pair", r.stdout), r.stdout
     if "--host-compare" in flags:
         assert "Grayscale ok!" in r.stdout
         assert ("Occlusion ok!" if "--fused" in flags else "Guided filter ok!") in r.stdout
@@ -169,7 +174,8 @@ def test_rccl_library_exports_the_exchange_step():
     assert os.path.exists(so), "libsmx_rccl.so not built (make -C stereo_matching_cuda_amd/csrc)"
     syms = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
     hdr = open(os.path.join(ROOT, "include", "smx_rccl.h")).read()
-    for name in ("smx_wta_allreduce", "smx_stereo_pair_sharded"):
+    for name in ("smx_wta_allreduce", "smx_wta_reduce", "smx_stereo_pair_sharded", "smx_sharded_create",
+                 "smx_sharded_run", "smx_sharded_destroy"):
         assert re.search(r"\bT %s\b" % name, syms), name
         assert re.search(r"\b%s\s*\(" % name, hdr), name
     assert "smx_wta_allreduce" in open(os.path.join(HOST, "winner_take_all.cuh")).read()
