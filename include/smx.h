@@ -190,10 +190,13 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
  * if the GPU is taken away mid-launch; the host-pointer wrappers call it for you. */
 int smx_dev_agg_status(const void* d_workspace);
 
-/* Aggregation implementation: 0 = auto (the fused single-kernel aggregation when radius <= 9,
- * else the multi-kernel path), 1 = force multi-kernel, 2 = force fused (error if radius > 9).
- * Process-wide; for tests and A/B timing.  smx_last_agg_path() reports which one the last
- * smx_dev_aggregate_wta[_pair] call on this thread used (1 or 2). */
+/* Aggregation implementation: 0 = auto (the fused single-kernel aggregation when radius <= 9, else the
+ * multi-kernel path), 1 = force multi-kernel, 2 = force fused (error if radius > 9), 3 = the round-2 fused
+ * kernel (kept for A/B timing), 4 = FAST: the fused kernel with wave-parallel row scans -- the additions of
+ * the row prefix sums are re-associated, so the results are NOT bit-exact (aggregated volume within 1e-4
+ * relative of the reference order, a handful of label flips per map: SURVEY App. C); an upper-bound point
+ * that is reported separately, never a default.  Process-wide; for tests and A/B timing.
+ * smx_last_agg_path() reports which one the last smx_dev_aggregate_wta[_pair] call on this thread used. */
 int smx_set_agg_path(int path);
 int smx_last_agg_path(void);
 /* Tile geometry of the fused aggregation for a box radius: output columns per strip, rows per band,

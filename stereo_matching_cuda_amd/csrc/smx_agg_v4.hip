@@ -392,11 +392,15 @@ __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(s
 #define LDS_RD64(dst, addr, imm) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
 
 // RT: compile-time box radius (RMAX) or -1 = the radius of the call (A.R <= RMAX)
-template <int SRC, int RT>
+// FAST: the non-bit-exact mode: the row prefix sums are wave-parallel DPP scans over the
+// columns of a row instead of the reference's sequential left -> right chain, i.e. the additions are
+// re-associated.  Reported separately, never the product default.
+template <int SRC, int RT, bool FAST>
 __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
     __shared__ __attribute__((aligned(16))) float ring1[RR * ROWF];   // stage-1 row y at ring row y mod RR
     __shared__ __attribute__((aligned(16))) float ring2[RR * ROWF];   // a/b row y at ring row (y + R) mod RR
     __shared__ __attribute__((aligned(16))) f2 cout[2][BH];         // row carries out
+    __shared__ __attribute__((aligned(16))) f2 cin_fast[FAST ? 2 : 1][FAST ? BH : 1];   // FAST: row carries in
     __shared__ float rcp_s[HWMAX * HWMAX + 1];                      // RN(1/area)
     __shared__ int s_item, s_next;
     __shared__ unsigned s_seen;                                     // last value read from the left neighbour's flag
@@ -714,6 +718,68 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
             else *co = acc;
         };
 
+        // ---- FAST mode: wave-parallel row scans.  The 4 BH (stage, row, component) scans of an iteration are
+        // dealt to all eight waves; one scan = an inclusive DPP prefix sum over ring columns jlo .. 63 (LANE =
+        // COLUMN), then over the columns 64 .. jhi-1 with the first part's total as carry.
+        auto wave_scan = [&](float x) {
+            // Hillis-Steele inside the 16-lane rows, then across them (row_bcast15 / row_bcast31)
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x111, 0xF, 0xF, false));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x112, 0xF, 0xF, false));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xF, 0xF, false));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xF, 0xF, false));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xA, 0xF, false));
+            x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xC, 0xF, false));
+            return x;
+        };
+        auto rowscans_fast = [&](int i, int rb, int rbp) {
+            // every wave takes 4 BH / NWAVE scans, four at a time (independent chains interleave); a scan that
+            // has nothing to do is predicated off, not branched around
+            constexpr int NU = 4 * BH / NWAVE, UB = 4;
+            static_assert(NU % UB == 0, "scans per wave");
+#pragma unroll
+            for (int ub = 0; ub < NU; ub += UB) {
+                float* row[UB];
+                float* co[UB];
+                float carry[UB], s0[UB], s1[UB], tot[UB];
+                int jlo[UB], jhi[UB], st[UB];
+                bool on[UB];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) {
+                    const int u = wave + NWAVE * (ub + k);
+                    st[k] = u / (2 * BH);
+                    const int srow = (u >> 1) % BH, scomp = u & 1;
+                    const int y = st[k] == 0 ? BH * i + srow : BH * (i - 1) - R + srow;
+                    jlo[k] = st[k] == 0 ? jlo1 : jlo2;
+                    jhi[k] = st[k] == 0 ? jhi1 : jhi2;
+                    on[k] = y >= 0 && y < h && jhi[k] > jlo[k] && (st[k] == 0 || i >= 1);       // wave-uniform
+                    int rr = (st[k] == 0 ? rb : rbp) + srow;
+                    rr = rr >= RR ? rr - RR : rr;
+                    row[k] = (st[k] == 0 ? ring1 : ring2) + rr * ROWF + scomp * OFF1;
+                    co[k] = (float*)&cout[st[k]][srow] + scomp;
+                    carry[k] = pred ? ((const float*)&cin_fast[st[k]][srow])[scomp] : 0.0f;
+                    s0[k] = on[k] && lane >= jlo[k] && lane < jhi[k] ? row[k][lane] : 0.0f;
+                    s1[k] = on[k] && 64 + lane < jhi[k] ? row[k][64 + lane] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < UB; ++k) s0[k] = wave_scan(s0[k]) + carry[k];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) tot[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, s0[k]), 63));
+#pragma unroll
+                for (int k = 0; k < UB; ++k) s1[k] = wave_scan(s1[k]) + tot[k];
+#pragma unroll
+                for (int k = 0; k < UB; ++k) {
+                    if (on[k] && lane >= jlo[k] && lane < jhi[k]) row[k][lane] = s0[k];
+                    if (on[k] && 64 + lane < jhi[k]) row[k][64 + lane] = s1[k];
+                    // the carry for the next strip: behind ring column OW-1 (stage 1) / behind the last column (stage 2)
+                    const int last = st[k] == 0 ? OW - 1 : jhi[k] - 1;
+                    if (on[k] && last >= jlo[k] && last < jhi[k]) {
+                        if (last < 64) { if (lane == last) *co[k] = s0[k]; }
+                        else if (lane == last - 64) *co[k] = s1[k];
+                    }
+                }
+            }
+        };
+
         // ---- column scan of one band for the dword `idx` (column, component) of this lane -------------------
         // rows yband + t at ring rows (rbase + t) mod RR; groups of four rows never wrap (RR % 4 == 0)
         auto colscan = [&](float* ring, int idx, int rbase, int yband, float& S) {
@@ -880,6 +946,12 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                     fetch_rec(i);
                 }
                 have_pref = false;
+                if (FAST && wave < NRSW && pred) {
+                    // the carries of this iteration: from the row-scan lanes' units to where every wave finds them
+                    const int st = sstage_of(), srow = srow_of(), scomp = scomp_of();
+                    const float c01 = scomp ? hreg.y : hreg.x, c23 = scomp ? hreg.w : hreg.z;
+                    ((float*)&cin_fast[st][srow])[scomp] = (srow & 1) ? c23 : c01;
+                }
             }
             issue_cost(i + 1);      // lands under the row scans (rows clamped: harmless behind the last iteration)
             V4_STAMP(1);
@@ -889,7 +961,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
             // ------------------------------------ R(i) --------------------------------------------------
             // the scans are dependent chains on the critical path of the iteration: let them win the issue
             // arbitration against the waves (of this and the other workgroup) that share their SIMDs
-            if (wave < NRSW) {
+            if (!FAST && wave < NRSW) {
                 __builtin_amdgcn_s_setprio(3);
                 rowscans(i, rb, rbp);
                 __builtin_amdgcn_s_setprio(0);
@@ -923,6 +995,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                 // memory before the barrier behind which one lane publishes it
                 drain_vmem();
             }
+            if (FAST) rowscans_fast(i, rb, rbp);
             V4_STAMP(3);
             wg_barrier();
             V4_STAMP(4);
@@ -1160,7 +1233,7 @@ size_t v4_workspace_bytes(int w, int h, int nslices) {
     return b + 16 * 256;
 }
 
-template <int SRC>
+template <int SRC, bool FAST>
 static int launch_walk4(const v4::Args& a, hipStream_t st) {
     int dev = 0, ncu = 256;
     SMX_HIP(hipGetDevice(&dev));
@@ -1173,9 +1246,9 @@ static int launch_walk4(const v4::Args& a, hipStream_t st) {
     const int slots = per_cu * ncu;
     const int grid = a.nitems < slots ? a.nitems : slots;
     if (a.R == v4::RMAX)
-        hipLaunchKernelGGL((v4::k_v4_walk<SRC, v4::RMAX>), dim3((unsigned)grid), dim3(v4::NT), 0, st, a);
+        hipLaunchKernelGGL((v4::k_v4_walk<SRC, v4::RMAX, FAST>), dim3((unsigned)grid), dim3(v4::NT), 0, st, a);
     else
-        hipLaunchKernelGGL((v4::k_v4_walk<SRC, -1>), dim3((unsigned)grid), dim3(v4::NT), 0, st, a);
+        hipLaunchKernelGGL((v4::k_v4_walk<SRC, -1, FAST>), dim3((unsigned)grid), dim3(v4::NT), 0, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
@@ -1216,7 +1289,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                  const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
                  const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
                  uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
-                 hipStream_t st, int* launches) {
+                 hipStream_t st, int* launches, bool fast) {
     const int R = p->radius;
     const V4Layout L = v4_layout(w, h, R);
     const bool use_cost = d_cost && d_cost[0];
@@ -1322,7 +1395,8 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         a.ticket = (unsigned*)ctrl; a.status = status;
         a.flags = (unsigned*)(ctrl + V4_CTRL_BYTES);
         SMX_HIP(hipMemsetAsync(ctrl, 0, v4_flag_bytes(L, a.nsv), st));
-        rc = use_cost ? launch_walk4<v4::SRC_COST>(a, st) : launch_walk4<v4::SRC_IMG>(a, st);
+        if (fast) rc = use_cost ? launch_walk4<v4::SRC_COST, true>(a, st) : launch_walk4<v4::SRC_IMG, true>(a, st);
+        else rc = use_cost ? launch_walk4<v4::SRC_COST, false>(a, st) : launch_walk4<v4::SRC_IMG, false>(a, st);
         if (rc) return rc;
         bool al8 = L.plane % 2 == 0;
         for (int v = 0; v < nviews; ++v) al8 = al8 && ((uintptr_t)wa.q[v] & 7) == 0;

@@ -18,7 +18,7 @@ static thread_local int g_launches = 0;
 #ifndef SMX_DEFAULT_AGG_PATH
 #define SMX_DEFAULT_AGG_PATH 0
 #endif
-static int g_agg_path = SMX_DEFAULT_AGG_PATH;   // 0 auto, 1 force multi-kernel, 2 force fused, 3 force the round-2 fused kernel
+static int g_agg_path = SMX_DEFAULT_AGG_PATH;   // 0 auto, 1 force multi-kernel, 2 force fused, 3 force the round-2 fused kernel, 4 fused FAST (not bit-exact)
 static thread_local int g_last_path = 0;
 
 // smx_agg_v3.hip
@@ -40,7 +40,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                  const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
                  const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
                  uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
-                 hipStream_t st, int* launches);
+                 hipStream_t st, int* launches, bool fast);
 void v4_geometry(int* ow, int* bh);
 
 // the fused aggregation: smx_agg_v4.hip, or its predecessor smx_agg_v3.hip when path 3 is forced (A/B timing)
@@ -53,7 +53,7 @@ static int aggregate_fused(const smx_params* p, int nviews, const uint8_t* const
         return aggregate_v3(p, nviews, d_guide, d_other, d_cost, w, h, dmin, s_begin, s_end, d_keys, d_mean_u8,
                             d_agg, d_ws, ws_bytes, st, launches);
     return aggregate_v4(p, nviews, d_guide, d_other, d_cost, w, h, dmin, s_begin, s_end, d_keys, d_mean_u8,
-                        d_agg, d_ws, ws_bytes, st, launches);
+                        d_agg, d_ws, ws_bytes, st, launches, g_agg_path == 4);
 }
 
 int fail(int code, const char* fmt, ...) {
@@ -163,7 +163,7 @@ size_t smx_agg_workspace_bytes(int w, int h, int nslices) {
 }
 
 int smx_set_agg_path(int path) {
-    if (path < 0 || path > 3) return fail(SMX_E_ARG, "smx_set_agg_path: path must be 0, 1, 2 or 3");
+    if (path < 0 || path > 4) return fail(SMX_E_ARG, "smx_set_agg_path: path must be 0 .. 4");
     g_agg_path = path;
     return SMX_OK;
 }
@@ -271,7 +271,7 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
             SMX_HIP(hipEventRecord(g_ev1, st));
             g_ev_valid = true;
         }
-        g_last_path = g_agg_path == 3 ? 3 : 2;
+        g_last_path = g_agg_path >= 3 ? g_agg_path : 2;
         return SMX_OK;
     }
     g_last_path = 1;
@@ -367,7 +367,7 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
             SMX_HIP(hipEventRecord(g_ev1, st));
             g_ev_valid = true;
         }
-        g_last_path = g_agg_path == 3 ? 3 : 2;
+        g_last_path = g_agg_path >= 3 ? g_agg_path : 2;
         return SMX_OK;
     }
     if (g_agg_path == 2)
@@ -616,7 +616,7 @@ int smx_ctx_stereo_pair(smx_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r
         if ((rc = aggregate_fused(p, 2, guide, other, want_cost ? cost : nullptr, w, h, dmin, 0, size_d, kv, mv,
                                   want_agg ? av : nullptr, c->ws.p, c->ws_bytes, st, &g_launches)))
             return rc;
-        g_last_path = g_agg_path == 3 ? 3 : 2;
+        g_last_path = g_agg_path >= 3 ? g_agg_path : 2;
     } else {
         if ((rc = smx_dev_aggregate_wta(p, dL, dR, want_cost ? c->costL.as<float>() : nullptr, w, h, dminl, 0, size_d,
                                         keysL, c->mean.as<uint8_t>(), want_agg ? c->aggLR.as<float>() : nullptr, c->ws.p,

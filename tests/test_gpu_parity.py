@@ -234,7 +234,7 @@ def _device_pair(Il, Ir, D, path=2, **kw):
     return pipe.results()
 
 
-@pytest.mark.parametrize("path", [2, 1])
+@pytest.mark.parametrize("path", [2, 1, 3])
 def test_device_pipeline_tsukuba_fused_cost(tsukuba_gray, tsukuba_oracle, path):
     Il, Ir = tsukuba_gray
     r = _device_pair(Il, Ir, 16, path=path, dminl=-15, dminr=0, want_agg=True)
@@ -697,3 +697,35 @@ def test_persistent_context_reuses_its_buffers(orc):
                     assert np.array_equal(got, ref), (seed, key)
     finally:
         smx.check(L.smx_destroy(ctx))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["tsukuba", "synthetic"])
+def test_fast_mode_is_close_but_not_bit_exact(tsukuba_gray, tsukuba_oracle, orc, shape):
+    """the FAST aggregation (smx_set_agg_path(4): wave-parallel row prefix sums,
+    i.e. re-associated additions) is reported separately and never the default.  What re-association costs
+    is the rounding noise of the integral image itself: an integral value is ~1e5 .. 1e6 at these sizes (ulp
+    0.01 .. 0.1) and a box mean divides a difference of four of them by 361, so the aggregated volume moves by
+    up to ~1e-3 relative (measured and printed; bound asserted: 5e-3) -- an order of magnitude more than the
+    1e-4 the survey hoped for -- and the labels flip where the two best costs of a pixel are closer than that
+    (the count is printed).  The exact mode pays for having neither."""
+    if shape == "tsukuba":
+        Il, Ir = tsukuba_gray
+        D, want, kw = 16, tsukuba_oracle, dict(dminl=-15, dminr=0)
+    else:
+        D = 40
+        Il, Ir = synth.gen_pair(330, 190, D, 77)
+        want, kw = orc.stereo_pair(Il, Ir, D, want_agg=True), {}
+    r = _device_pair(Il, Ir, D, path=4, want_agg=True, **kw)
+    flips = {}
+    for v in "lr":
+        got, ref = np.asarray(r["agg" + v], np.float64), np.asarray(want["agg" + v], np.float64).reshape(r["agg" + v].shape)
+        rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
+        assert rel.max() <= 5e-3, (v, rel.max())
+        worst = max(locals().get("worst", 0.0), float(rel.max()))
+        flips[v] = int((np.asarray(r["dmap" + v]) != np.asarray(want["dmap" + v]).reshape(r["dmap" + v].shape)).sum())
+        assert np.array_equal(r["mean" + v], np.asarray(want["mean" + v]).reshape(r["mean" + v].shape))
+    n = Il.size
+    print(f"FAST mode on {shape}: largest relative deviation of the aggregated volume {worst:.2e}; "
+          f"label flips left {flips['l']} / right {flips['r']} of {n} pixels")
+    assert max(flips.values()) <= n // 500      # far fewer in practice
