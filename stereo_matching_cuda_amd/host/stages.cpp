@@ -65,7 +65,11 @@ void compute_cost(unsigned char* i1, unsigned char* i2, float* cost, int w1, int
     if (host_gpu_compare) {
         std::vector<float> twin((size_t)size_d * w1 * h1);
         costVolumeOnCPU(i1, i2, twin.data(), w1, w2, h1, h2, size_d, dmin);
-        if (check_errors(twin.data(), cost, size_d * w1 * h1)) cout << "Cost volume ok!" << endl;
+        // (the reference-signature check_errors takes an int count: volumes beyond 2^31 cells are compared in planes)
+        bool ok = true;
+        for (int z = 0; z < size_d; ++z)
+            ok = check_errors(twin.data() + (size_t)z * w1 * h1, cost + (size_t)z * w1 * h1, w1 * h1) && ok;
+        if (ok) cout << "Cost volume ok!" << endl;
     }
 }
 

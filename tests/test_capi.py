@@ -132,3 +132,25 @@ def test_fast_division_is_exhaustively_bit_identical_to_ieee(tmp_path):
                            os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_fastdiv.c"), "-lm", "-o", exe])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and " bad 0" in r.stdout, r.stdout
+
+
+def test_integration_md_c_snippets_compile_against_the_headers(tmp_path):
+    """Every ```cpp block of INTEGRATION.md that includes smx.h / smx_rccl.h is real code: it must pass
+    g++ -fsyntax-only against include/ (the boundary document cannot drift from the headers again)."""
+    import re
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.join(os.path.dirname(__file__), "..")
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```cpp\n(.*?)```", text, re.S) if '#include "smx' in b]
+    assert len(blocks) >= 4, "expected the context, stream, one-rank and sharded snippets"
+    for k, b in enumerate(blocks):
+        if '#include "smx.h"' in b and "CHECK(" in b:
+            continue                      # the stages.cpp excerpt: compiled as part of host/stages.cpp
+        src = tmp_path / f"snippet{k}.cpp"
+        src.write_text("#include <stdint.h>\n#include <stddef.h>\n" + b)
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                            str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, f"snippet {k}:\n{b}\n{r.stderr}"

@@ -232,6 +232,57 @@ def test_png_reader_rejects_malformed_files(tmp_path):
         assert out.returncode == 0 and out.stdout.strip() == want, (name, out.stdout, out.stderr)
 
 
+def test_host_layer_and_oracle_under_sanitizers(tmp_path):
+    """SURVEY 5 (sanitizers): the CPU twins of host/cpu_twins.cpp, the PNG / PFM code of host/png_io.cpp and the
+    oracle, all compiled with -fsanitize=address,undefined (-fno-sanitize-recover): the twins equal the oracle
+    bit for bit on a seeded pair, the PNG reader survives malformed files, and no sanitizer report appears.
+    CPU only (no GPU sanitizer runs on this pool)."""
+    import shutil
+    import struct
+    import zlib
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "sanitize_check")
+    san = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g"]
+    obj = str(tmp_path / "oracle.o")
+    subprocess.check_call(["gcc", "-O1", "-ffp-contract=off", "-c", os.path.join(ROOT, "oracle", "smx_oracle.c"), "-o", obj] + san)
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + HOST,
+                           os.path.join(ROOT, "tests", "host_sanitize_check.cpp"), os.path.join(HOST, "cpu_twins.cpp"),
+                           os.path.join(HOST, "png_io.cpp"), obj, "-o", exe, "-lz"] + san)
+    sig = b"\x89PNG\r\n\x1a\n"
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    ihdr = struct.pack(">IIBBBBB", 2, 2, 8, 0, 0, 0, 0)
+    idat = zlib.compress(b"\x00\x01\x02\x00\x03\x04")
+    cases = {
+        "ok.png": (sig + chunk(b"IHDR", ihdr) + chunk(b"IDAT", idat) + chunk(b"IEND", b""), "loaded"),
+        "short_ihdr.png": (sig + chunk(b"IHDR", ihdr[:5]) + chunk(b"IEND", b""), "rejected"),
+        "huge.png": (sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 0x7FFFFFFF, 0x7FFFFFFF, 8, 0, 0, 0, 0)) +
+                     chunk(b"IDAT", idat) + chunk(b"IEND", b""), "rejected"),
+        "short_idat.png": (sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 64, 64, 8, 2, 0, 0, 0)) + chunk(b"IDAT", idat) +
+                           chunk(b"IEND", b""), "rejected"),
+        "bad_filter.png": (sig + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(b"\x09\x01\x02\x07\x03\x04")) +
+                           chunk(b"IEND", b""), None),
+        "garbage_idat.png": (sig + chunk(b"IHDR", ihdr) + chunk(b"IDAT", b"\x00" * 40) + chunk(b"IEND", b""), "rejected"),
+        "truncated.png": (sig + chunk(b"IHDR", ihdr)[:-3], "rejected"),
+        "chunk_len_overflow.png": (sig + struct.pack(">I", 0xFFFFFFF0) + b"IHDR" + ihdr, "rejected"),
+    }
+    files = []
+    for name, (blob, _) in cases.items():
+        (tmp_path / name).write_bytes(blob)
+        files.append(str(tmp_path / name))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, str(tmp_path)] + files, capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "MISMATCH" not in r.stdout and "runtime error" not in r.stderr and "AddressSanitizer" not in r.stderr, r.stdout + r.stderr
+    for what in ("gray", "cost volume", "integral", "guided filter best", "guided filter dmap", "guided filter mean",
+                 "detect occlusion", "fill occlusion", "png round trip"):
+        assert "ok " + what in r.stdout, r.stdout
+    for name, (_, want) in cases.items():
+        if want:
+            assert f"{want} {tmp_path / name}" in r.stdout, (name, r.stdout)
+
+
 @pytest.mark.gpu
 def test_drop_in_main_reproduces_the_committed_images(binary, golden, tmp_path):
     PIL = pytest.importorskip("PIL.Image")
