@@ -117,6 +117,14 @@ __device__ __forceinline__ float div_small_int(float x, float d, float r) {
     float e = __builtin_fmaf(-q, d, x);
     return __builtin_fmaf(e, r, q);
 }
+// the same for both components of a cell at once: v_pk_mul_f32 + 2 v_pk_fma_f32 (elementwise, each rounded once:
+// bit-identical to the scalar form)
+__device__ __forceinline__ f2 div_small_int2(f2 x, float d, float r) {
+    const f2 d2 = {d, d}, r2 = {r, r};
+    f2 q = x * r2;
+    f2 e = __builtin_elementwise_fma(-q, d2, x);
+    return __builtin_elementwise_fma(e, r2, q);
+}
 __device__ __forceinline__ bool div_needs_exact(float x) {
     const float ax = fabsf(x);
     return !(ax >= 0x1p-100f && ax < __builtin_inff());   // tiny, zero, inf or NaN
@@ -380,6 +388,14 @@ __device__ unsigned long long g_itemlog[3 * ITEMLOG_MAX];
 #endif
 
 constexpr unsigned FLAG_DONE = 0x7fffffffu;
+// Diagnostic build only (-DSMX_V4_WHATIF=<bits>): leaves parts of the work out (WRONG results) to see what
+// the kernel time is sensitive to.  1: no q stores / guidance loads in X; 2: box taps not read from LDS;
+// 4: no cost evaluation; 8: no column scans; 16: no row scans; 32: no stage-1 cost loads; 64: no box at all;
+// 128: no exact-division check; 256: no division; 512: no stage-1 box; 1024: no stage-2 box
+#ifndef SMX_V4_WHATIF
+#define SMX_V4_WHATIF 0
+#endif
+constexpr int WHATIF = SMX_V4_WHATIF;
 
 // A value the compiler must re-derive where it is used: per-lane constants of the whole item (lane geometry,
 // unit indices) are recomputed from the lane index in a few VALU instructions instead of living in VGPRs
@@ -390,6 +406,10 @@ __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(s
 // one ds_read_b64 the compiler cannot pair into a ds_read2_b64 (which takes four times the LDS cycles of two
 // ds_read_b64 for the same bytes); the caller waits with lds_wait16() before the first use
 #define LDS_RD64(dst, addr, imm) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
+// a cell's (first, second) component of a component-planar ring row as ONE register pair: the compiler would pair
+// the loads of a row by tap instead (both taps of a component per instruction) and then shuffle eight registers
+#define LDS_RD2(dst, addr, o0, o1) \
+    asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "i"(o0), "i"(o1))
 
 // RT: compile-time box radius (RMAX) or -1 = the radius of the call (A.R <= RMAX)
 // FAST: the non-bit-exact mode: the row prefix sums are wave-parallel DPP scans over the
@@ -470,7 +490,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
         const int xs = k * OW;
         const int cs1 = xs - R - 1;             // image column of ring-1 column 0
         const int cs2 = xs - HW;                // image column of ring-2 column 0
-        const bool pred = k > 0, succ = k + 1 < K;
+        const bool pred = k > 0 && !(WHATIF & 2048), succ = k + 1 < K && !(WHATIF & 2048);   // (2048: no hand-off between strips)
         const int d = V.d0 + slice;
         unsigned* const myflag = A.flags + (size_t)sv * K + k;
         const size_t recs = (size_t)NI * REC_F2;      // float2 per (parity, slice-view)
@@ -825,14 +845,35 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
             rb0 = rb0 >= RR ? rb0 - RR : rb0;            // the wave's group of RPW bottom rows never wraps
             rb0 += 2 * half;
             f2 s11[2], s10[2], s01[2], s00[2], val[2];
+            if (RT == RMAX && !(WHATIF & 2)) {
+                static_assert(HWMAX + OFF1 < 256, "ds_read2_b32 offsets");
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                int rt = rb0 + t - HW;
-                rt = rt < 0 ? rt + RR : rt;
-                const float* pb = ring + (rb0 + t) * ROWF + lane;
-                const float* pt = ring + rt * ROWF + lane;
-                s11[t] = cell(pb + HW); s10[t] = cell(pb);
-                s01[t] = cell(pt + HW); s00[t] = cell(pt);
+                for (int t = 0; t < 2; ++t) {
+                    int rt = rb0 + t - HW;
+                    rt = rt < 0 ? rt + RR : rt;
+                    const unsigned ab = lds_off(ring + (rb0 + t) * ROWF + lane), at = lds_off(ring + rt * ROWF + lane);
+                    LDS_RD2(s11[t], ab, HWMAX, HWMAX + OFF1);
+                    LDS_RD2(s10[t], ab, 0, OFF1);
+                    LDS_RD2(s01[t], at, HWMAX, HWMAX + OFF1);
+                    LDS_RD2(s00[t], at, 0, OFF1);
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(s11[0]), "+v"(s10[0]), "+v"(s01[0]), "+v"(s00[0]), "+v"(s11[1]), "+v"(s10[1]), "+v"(s01[1]),
+                               "+v"(s00[1]));
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    int rt = rb0 + t - HW;
+                    rt = rt < 0 ? rt + RR : rt;
+                    const float* pb = ring + (rb0 + t) * ROWF + lane;
+                    const float* pt = ring + rt * ROWF + lane;
+                    if (WHATIF & 2) {
+                        s11[t] = s10[t] = s01[t] = s00[t] = (f2){(float)(rb0 + lane), 2.0f + rt};
+                    } else {
+                        s11[t] = cell(pb + HW); s10[t] = cell(pb);
+                        s01[t] = cell(pt + HW); s00[t] = cell(pt);
+                    }
+                }
             }
             float amin = __builtin_inff(), amax = 0.0f;
 #pragma unroll
@@ -841,13 +882,12 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                 v = v - s01[t];
                 v = v + s00[t];
                 val[t] = v;
-                m[t].x = div_small_int(v.x, area_full, ra_full);
-                m[t].y = div_small_int(v.y, area_full, ra_full);
+                m[t] = (WHATIF & 256) ? v : div_small_int2(v, area_full, ra_full);
                 amin = fminf(amin, fminf(fabsf(v.x), fabsf(v.y)));
                 amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
             }
             // tiny, zero, infinite window sums (a NaN sum gives a NaN mean on either path)
-            if (__any(!(amin >= 0x1p-100f) || !(amax < __builtin_inff()))) {
+            if (!(WHATIF & 128) && __any(!(amin >= 0x1p-100f) || !(amax < __builtin_inff()))) {
                 asm volatile("; exact-division slow path");   // keep this a real (rare) wave-uniform branch
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
@@ -895,6 +935,19 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                     m[t].y = 1.0f * v.y / area;
                 }
             }
+        };
+
+        // q rows of X(iq)
+        float qout[RPW];
+        bool qok[RPW];
+        auto store_q = [&](int iq) {
+            if (WHATIF & 1) return;
+            const unsigned vq = vq_of();
+            const int yq0 = BH * (iq - 1) - 2 * R + RPW * wave;
+#pragma unroll
+            for (int t = 0; t < RPW; ++t)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qout[t]), r_q, (int)(qok[t] ? vq : OOB),
+                                                      min(max(yq0 + t, 0), h - 1) * (int)w4, AUX_NT);
         };
 
         // ===================================== the band loop ==============================================
@@ -953,7 +1006,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                     ((float*)&cin_fast[st][srow])[scomp] = (srow & 1) ? c23 : c01;
                 }
             }
-            issue_cost(i + 1);      // lands under the row scans (rows clamped: harmless behind the last iteration)
+            if (!(WHATIF & 32)) issue_cost(i + 1);      // lands under the row scans (rows clamped: harmless behind the last iteration)
             V4_STAMP(1);
             wg_barrier();
             V4_STAMP(2);
@@ -963,7 +1016,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
             // arbitration against the waves (of this and the other workgroup) that share their SIMDs
             if (!FAST && wave < NRSW) {
                 __builtin_amdgcn_s_setprio(3);
-                rowscans(i, rb, rbp);
+                if (!(WHATIF & 16)) rowscans(i, rb, rbp);
                 __builtin_amdgcn_s_setprio(0);
             } else {
                 if (wave == NWAVE - 1 && lane == 0) {
@@ -973,7 +1026,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                     if (i == NI - 1)
                         s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                eval_cost();
+                if (!(WHATIF & 4)) eval_cost();
                 // the left neighbour's last 2R+1 columns of the stage-2 integral of band i-1 -> ring 2 (nobody
                 // touches these columns before X(i))
                 int hu_r, hu_c;
@@ -1006,12 +1059,12 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
             if (wave < 3) {
                 __builtin_amdgcn_s_setprio(3);
                 const int cidx1 = 64 * wave + opaque(lane);                      // stage 1: every dword of a row
-                if (cidx1 < ROWF) colscan(ring1, cidx1, rb, BH * i, Sc);
+                if (cidx1 < ROWF && !(WHATIF & 8)) colscan(ring1, cidx1, rb, BH * i, Sc);
                 __builtin_amdgcn_s_setprio(0);
             } else if (wave < 5) {
                 __builtin_amdgcn_s_setprio(3);
                 const int cidx2 = OFF1 * (wave - 3) + HW + opaque(lane);         // stage 2: the new columns of either plane
-                if (i >= 1) colscan(ring2, cidx2, rbp, BH * (i - 1) - R, Sc);
+                if (i >= 1 && !(WHATIF & 8)) colscan(ring2, cidx2, rbp, BH * (i - 1) - R, Sc);
                 __builtin_amdgcn_s_setprio(0);
             }
             V4_STAMP(5);
@@ -1039,7 +1092,10 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                 const int ya0 = BH * i - R + RPW * wave;
                 f2 m[RPW];
                 bool ok[RPW];
-                if (xint1 && BH * i - 2 * R - 1 >= 0 && BH * i + BH <= h) {
+                if (WHATIF & (64 | 512)) {
+#pragma unroll
+                    for (int t = 0; t < RPW; ++t) m[t] = (f2){1.0f + lane, 2.0f};
+                } else if (xint1 && BH * i - 2 * R - 1 >= 0 && BH * i + BH <= h) {
                     box4_fast(ring1, rb, m);
                 } else {
                     box4_gen(ring1, 0, mkgeo(xs + opaque(lane), cs1), xint1, ya0, m, ok);
@@ -1054,15 +1110,16 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                 }
             }
             V4_STAMP(9);
-            float qout[RPW];
-            bool qok[RPW];
             const int yq0 = BH * (i - 1) - 2 * R + RPW * wave;
 #pragma unroll
             for (int t = 0; t < RPW; ++t) { qout[t] = 0.0f; qok[t] = false; }
             if (i >= 1) {
                 // box means of stage 2 -> q rows [BH (i-1) - 2R, BH i - 2R)
                 f2 m[RPW];
-                if (xint2 && BH * (i - 1) - 3 * R - 1 >= 0 && BH * i - R <= h) {
+                if (WHATIF & (64 | 1024)) {
+#pragma unroll
+                    for (int t = 0; t < RPW; ++t) m[t] = (f2){1.0f + lane, 2.0f};
+                } else if (xint2 && BH * (i - 1) - 3 * R - 1 >= 0 && BH * i - R <= h) {
                     box4_fast(ring2, rbp, m);
 #pragma unroll
                     for (int t = 0; t < RPW; ++t) qok[t] = true;
@@ -1079,13 +1136,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
             V4_STAMP(10);
             __builtin_amdgcn_sched_barrier(0);
             // ---- the global accesses of the phase: q rows, record i, the loads of iteration i+1 ----
-            if (i >= 1) {
-                const unsigned vq = vq_of();
-#pragma unroll
-                for (int t = 0; t < RPW; ++t)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qout[t]), r_q, (int)(qok[t] ? vq : OOB),
-                                                          min(max(yq0 + t, 0), h - 1) * (int)w4, AUX_NT);
-            }
+            if (i >= 1) store_q(i);
             if (succ && (hu_halo || hu_carry)) {
                 // record i: row carries of this iteration's row scans, last 2R+1 columns of the stage-2 integral
                 f4 hov;
@@ -1103,7 +1154,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                 st16_sc1(r_out, (unsigned)((i * REC_F2) * 8) + hu_off(), hov);
             }
             __builtin_amdgcn_sched_barrier(0);
-            issue_guid(i + 1);      // (rows are clamped into the image: harmless behind the last iteration)
+            if (!(WHATIF & 1)) issue_guid(i + 1);      // (rows are clamped into the image: harmless behind the last iteration)
             V4_STAMP(7);
             wg_barrier();
             rbp = rb;
