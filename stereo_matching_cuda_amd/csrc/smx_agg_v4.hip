@@ -224,57 +224,82 @@ struct GuidArgs {
     uint8_t* mean_u8[2];    // out, optional: mean_I as u8 (flToChOnGPU guidedFilter.cu:451-458)
 };
 
-// Row prefix sums (rowSum integral.cu:78-90).  One wave per 16 rows of one view; lanes 0..31 = (row, plane).
-// The 16 x 64 tiles are loaded and stored with LANE = COLUMN (coalesced) and turned through LDS.
-constexpr int GR_ROWS = 16;
-__global__ __launch_bounds__(64) void k_v4_guid_rows(GuidArgs ga, int w, int h) {
-    __shared__ float tile[2][GR_ROWS][65];
-    const int lane = threadIdx.x, view = blockIdx.y, y0 = blockIdx.x * GR_ROWS;
+// Row prefix sums (rowSum integral.cu:78-90).  One workgroup per `rows` image rows of one view, whole rows in
+// LDS: (1) all loads, (2) lanes (row, plane) of wave 0 run the sequential prefix 64 columns at a time through
+// registers, (3) all stores.  No wait for a load ever has a store in front of it (a wave's accesses complete in
+// order: a scan that loads and stores tile by tile waits for the acknowledgement of its stores in every tile).
+// Dynamic LDS: 2 planes x rows x wpad floats, wpad = roundup(w, 128) + 4.
+constexpr int GR_NT = 256;
+constexpr int GR_MAXROWS = 8;
+__host__ __device__ inline int gr_wpad(int w) { return ((w + 127) & ~127) + 4; }
+__global__ __launch_bounds__(GR_NT) void k_v4_guid_rows(GuidArgs ga, int w, int h, int rows) {
+    extern __shared__ __attribute__((aligned(16))) float gr_lds[];
+    const int tid = threadIdx.x, view = blockIdx.y, y0 = blockIdx.x * rows;
     const fg_t* __restrict__ FG = ga.FG[view];
     float* __restrict__ S0 = ga.S[view][0];
     float* __restrict__ S1 = ga.S[view][1];
     const int wp = w + 2 * PADX;
-    const int srow = lane & 15, spl = (lane >> 4) & 1;
-    float acc = -0.0f;                                   // exact additive identity
-    float v[GR_ROWS];
-    auto load = [&](int x0) {
+    const int wpad = gr_wpad(w), wr = wpad - 4;               // wr: a multiple of 128
+    float* P0 = gr_lds;
+    float* P1 = gr_lds + rows * wpad;
+    // (1) the rows of this workgroup, 16 loads per thread in flight
+    const int total = rows * wr;
+    for (int e0 = 0; e0 < total; e0 += 16 * GR_NT) {
+        float v[16];
 #pragma unroll
-        for (int r = 0; r < GR_ROWS; ++r) {
-            const int y = min(y0 + r, h - 1), x = min(x0 + lane, w - 1);
-            v[r] = (float)FG[(size_t)y * wp + PADX + x].x;      // chToFlOnGPU guidedFilter.cu:442-449
+        for (int k = 0; k < 16; ++k) {
+            const int e = min(e0 + k * GR_NT + tid, total - 1);
+            const int r = e / wr, x = e - r * wr;
+            v[k] = (float)FG[(size_t)min(y0 + r, h - 1) * wp + PADX + min(x, w - 1)].x;      // chToFlOnGPU guidedFilter.cu:442-449
         }
-    };
-    load(0);
-    for (int x0 = 0; x0 < w; x0 += 64) {
 #pragma unroll
-        for (int r = 0; r < GR_ROWS; ++r) {
-            tile[0][r][lane] = v[r];
-            tile[1][r][lane] = v[r] * v[r];              // pixelMultOnGPU(d_im, d_im) :111
-        }
-        if (x0 + 64 < w) load(x0 + 64);                  // in flight under the scan
-        __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): the tile is in LDS (one wave: no barrier)
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 32) {
-            const int nc = min(64, w - x0);
-            float* row = &tile[spl][srow][0];
-            for (int c = 0; c < nc; ++c) {
-                acc = row[c] + acc;
-                row[c] = acc;
+        for (int k = 0; k < 16; ++k) {
+            const int e = e0 + k * GR_NT + tid;
+            if (e < total) {
+                const int r = e / wr, x = e - r * wr;
+                P0[r * wpad + x] = v[k];
+                P1[r * wpad + x] = v[k] * v[k];               // pixelMultOnGPU(d_im, d_im) :111
             }
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        if (x0 + lane < w) {
+    }
+    __syncthreads();
+    // (2) columns behind the image hold copies of the last pixel; their sums are never stored
+    if (tid < 2 * rows) {
+        float* row = gr_lds + tid * wpad;                     // tid = plane * rows + row
+        float acc = -0.0f;                                    // exact additive identity
+        f4 c[16], n[16];
+        auto rd = [&](f4 (&t)[16], int x0) {
 #pragma unroll
-            for (int r = 0; r < GR_ROWS; ++r) {
-                if (y0 + r < h) {
-                    S0[(size_t)(y0 + r) * w + x0 + lane] = tile[0][r][lane];
-                    S1[(size_t)(y0 + r) * w + x0 + lane] = tile[1][r][lane];
-                }
+            for (int k = 0; k < 16; ++k) t[k] = *(const f4*)(row + x0 + 4 * k);
+        };
+        auto scan_wr = [&](f4 (&t)[16], int x0) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                acc = t[k].x + acc; t[k].x = acc;
+                acc = t[k].y + acc; t[k].y = acc;
+                acc = t[k].z + acc; t[k].z = acc;
+                acc = t[k].w + acc; t[k].w = acc;
             }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) *(f4*)(row + x0 + 4 * k) = t[k];
+        };
+        rd(c, 0);
+        for (int x0 = 0; x0 < wr; x0 += 128) {
+            rd(n, x0 + 64);
+            scan_wr(c, x0);
+            rd(c, min(x0 + 128, wr - 64));                    // (behind the last pair: a harmless re-read)
+            scan_wr(n, x0 + 64);
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (int r = 0; r < rows; ++r) {
+        if (y0 + r >= h) break;
+        float* d0 = S0 + (size_t)(y0 + r) * w;
+        float* d1 = S1 + (size_t)(y0 + r) * w;
+        for (int x = tid; x < w; x += GR_NT) {
+            d0[x] = P0[r * wpad + x];
+            d1[x] = P1[r * wpad + x];
+        }
     }
 }
 
@@ -362,6 +387,8 @@ __device__ unsigned long long g_stamps[NWAVE * STAMP_SLOTS];
         if (item == SMX_V4_STAMPS && lane == 0 && i * STAMP_W + (n) < STAMP_SLOTS)            \
             g_stamps[wave * STAMP_SLOTS + i * STAMP_W + (n)] = __builtin_amdgcn_s_memtime();  \
     } while (0)
+#elif defined(SMX_V4_MARK)
+#define V4_STAMP(n) asm volatile("; V4_MARK " #n)      // (to find the phases in the ISA listing)
 #else
 #define V4_STAMP(n) ((void)0)
 #endif
@@ -388,10 +415,19 @@ __device__ unsigned long long g_itemlog[3 * ITEMLOG_MAX];
 #endif
 
 constexpr unsigned FLAG_DONE = 0x7fffffffu;
+// Hand-in hysteresis (experiment, default off): an item that has caught up with its left neighbour meets the slow
+// hand-in -- poll, barrier, exposed cross-XCD load -- in every iteration; with SLACK > 0 it waits once until the
+// neighbour is SLACK records ahead.  Measured on KITTI (1242x375, D=192): SLACK 0 / 2 / 3 / 5 / 8 -> 1.266 / 1.274 /
+// 1.274 / 1.279 / 1.280 ms per pair: the slow hand-in is not what a caught-up item loses time on.
+#ifndef SMX_V4_SLACK
+#define SMX_V4_SLACK 0
+#endif
+constexpr unsigned SLACK = SMX_V4_SLACK;
 // Diagnostic build only (-DSMX_V4_WHATIF=<bits>): leaves parts of the work out (WRONG results) to see what
 // the kernel time is sensitive to.  1: no q stores / guidance loads in X; 2: box taps not read from LDS;
 // 4: no cost evaluation; 8: no column scans; 16: no row scans; 32: no stage-1 cost loads; 64: no box at all;
-// 128: no exact-division check; 256: no division; 512: no stage-1 box; 1024: no stage-2 box
+// 128: no exact-division check; 256: no division; 512: no stage-1 box; 1024: no stage-2 box; 2048: no hand-off
+// between strips; 4096: the row-scan wave never waits for the neighbour's record
 #ifndef SMX_V4_WHATIF
 #define SMX_V4_WHATIF 0
 #endif
@@ -652,7 +688,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
             rr = rr >= RR ? rr - RR : rr;
             // the unit holds the carries (p, I p) / (a, b) of rows 2k, 2k+1
             const float c01 = scomp ? hreg.y : hreg.x, c23 = scomp ? hreg.w : hreg.z;
-            float acc = pred ? ((srow & 1) ? c23 : c01) : -0.0f;
+            float acc = (pred && !(WHATIF & 4096)) ? ((srow & 1) ? c23 : c01) : -0.0f;   // (4096: wave 0 never waits for the record)
 #ifdef SMX_V4_STAMPS
             asm volatile("" : "+v"(acc));
             V4_STAMP(11);
@@ -956,7 +992,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
         issue_cost(0);
         issue_guid(0);
         if (pred) {
-            if (tid == 0) spin_pred(1u);
+            if (tid == 0) spin_pred(1u + SLACK);
             wg_barrier();
             seen = s_seen;
         }
@@ -993,7 +1029,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                 }
                 if (pred && !have_pref) {
                     // the neighbour had not published record i when this item looked: wait for it now
-                    if (tid == 0) spin_pred((unsigned)i + 1u);
+                    if (tid == 0) spin_pred((unsigned)i + 1u + SLACK);
                     wg_barrier();
                     seen = s_seen;
                     fetch_rec(i);
@@ -1410,7 +1446,20 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             ga.G[v] = gpair[v];
             ga.mean_u8[v] = d_mean_u8 ? d_mean_u8[v] : nullptr;
         }
-        hipLaunchKernelGGL(v4::k_v4_guid_rows, dim3(cdivu4(h, v4::GR_ROWS), nviews), dim3(64), 0, st, ga, w, h);
+        {
+            // rows per workgroup: few enough that the launch fills the chip, and whole rows fit the LDS
+            const int wpad = v4::gr_wpad(w);
+            int rows = (int)((size_t)(152 * 1024) / ((size_t)8 * wpad));
+            const int fillrows = h * nviews / 256;
+            rows = rows > fillrows ? fillrows : rows;
+            rows = rows > v4::GR_MAXROWS ? v4::GR_MAXROWS : rows;
+            rows = rows < 1 && (size_t)8 * wpad <= (size_t)(152 * 1024) ? 1 : rows;
+            if (rows < 1) return fail(SMX_E_ARG, "aggregate_v4: image too wide for the guidance row scan");
+            // (per device, so not cached in a static: the sharded driver runs several devices from one process)
+            SMX_HIP(hipFuncSetAttribute((const void*)v4::k_v4_guid_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            hipLaunchKernelGGL(v4::k_v4_guid_rows, dim3(cdivu4(h, rows), nviews), dim3(v4::GR_NT), (size_t)8 * rows * wpad, st,
+                               ga, w, h, rows);
+        }
         hipLaunchKernelGGL(v4::k_v4_guid_cols, dim3(cdivu4(w, 64), 2, nviews), dim3(64), 0, st, ga, w, h);
         hipLaunchKernelGGL(v4::k_v4_guid_finish, dim3(cdivu4(w, 256), h, nviews), dim3(256), 0, st, ga, w, h, R, p->eps);
         SMX_HIP(hipGetLastError());
