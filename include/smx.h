@@ -222,7 +222,8 @@ int smx_dev_fill_occlusion(float* d_disp, int w, int h, float vMin, void* stream
  * view in [0, n) and the right one in [n, 2n), n = w*h.  best <- preset, dmap <- 0, the winning slice of
  * every key applied (smx_dev_init_wta + smx_dev_apply_keys), d_occlusion <- left map after the LR check
  * (smx_dev_detect_occlusion with dOcclusion), d_filled <- d_occlusion filled (smx_dev_fill_occlusion with
- * vMin).  Three launches instead of seven; same results (tested against the per-call sequence). */
+ * vMin).  One launch (three for rows of more than 8192 pixels) instead of seven; same results (tested against
+ * the per-call sequence). */
 int smx_dev_finish_pair(const smx_params* p, const int64_t* d_keys, int w, int h, int dminl, int dminr,
                         int dOcclusion, float vMin, float* d_best, float* d_dmap, float* d_occlusion,
                         float* d_filled, void* stream);

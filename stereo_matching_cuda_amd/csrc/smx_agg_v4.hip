@@ -187,9 +187,18 @@ constexpr int PADX = 4;                 // the aggregation loads four columns pe
 struct PrepArgs {
     const uint8_t* I[2];
     fg_t* FG[2];
+    unsigned* zero[2];      // two word ranges this launch clears (status word, control block of the first chunk):
+    unsigned nzero[2];      // saves two fill launches per call
 };
 
 __global__ void k_v4_prep(PrepArgs pa, int w, int h) {
+    if (blockIdx.z == 0) {
+        const unsigned gid = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        const unsigned gsz = gridDim.y * gridDim.x * blockDim.x;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            for (unsigned i = gid; i < pa.nzero[r]; i += gsz) pa.zero[r][i] = 0u;
+    }
     const uint8_t* __restrict__ I = pa.I[blockIdx.z];
     fg_t* __restrict__ FG = pa.FG[blockIdx.z];
     const int xp = blockIdx.x * blockDim.x + threadIdx.x;   // padded column
@@ -1399,7 +1408,6 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     // first 256 B: status word of the call (smx_dev_agg_status)
     unsigned* status = (unsigned*)carve(256);
     if (oom) return fail(SMX_E_WS, "aggregate_v4: workspace too small");
-    SMX_HIP(hipMemsetAsync(status, 0, 256, st));
     // fixed part: image planes, guidance statistics, guidance scratch
     v4::fg_t* FG[2];
     float* gs[4];
@@ -1432,6 +1440,8 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     pa.I[1] = nviews == 2 ? d_guide[1] : (d_other ? d_other[0] : nullptr);
     pa.FG[0] = FG[0]; pa.FG[1] = FG[1];
     const int nimg = pa.I[1] ? 2 : 1;
+    pa.zero[0] = status; pa.nzero[0] = 64;
+    pa.zero[1] = (unsigned*)ctrl; pa.nzero[1] = (unsigned)(v4_flag_bytes(L, nsv_max) / 4);
     hipLaunchKernelGGL(v4::k_v4_prep, dim3(cdivu4(w + 2 * v4::PADX, 256), h, nimg), dim3(256), 0, st, pa, w, h);
     SMX_HIP(hipGetLastError());
     ++nl;
@@ -1494,7 +1504,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         a.hand = hand;
         a.ticket = (unsigned*)ctrl; a.status = status;
         a.flags = (unsigned*)(ctrl + V4_CTRL_BYTES);
-        SMX_HIP(hipMemsetAsync(ctrl, 0, v4_flag_bytes(L, a.nsv), st));
+        if (s0 != s_begin) SMX_HIP(hipMemsetAsync(ctrl, 0, v4_flag_bytes(L, a.nsv), st));   // (first chunk: cleared by k_v4_prep)
         if (fast) rc = use_cost ? launch_walk4<v4::SRC_COST, true>(a, st) : launch_walk4<v4::SRC_IMG, true>(a, st);
         else rc = use_cost ? launch_walk4<v4::SRC_COST, false>(a, st) : launch_walk4<v4::SRC_IMG, false>(a, st);
         if (rc) return rc;
@@ -1507,7 +1517,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             hipLaunchKernelGGL(v4::k_v4_wta, dim3(cdivu4((int64_t)L.plane, 256), nviews), dim3(256), 0, st, wa,
                                L.plane, cnt, s0);
         SMX_HIP(hipGetLastError());
-        nl += 3;
+        nl += s0 != s_begin ? 3 : 2;
     }
     if (launches) *launches = nl;
     return SMX_OK;

@@ -243,6 +243,10 @@ int smx_dev_finish_pair(const smx_params* p, const int64_t* d_keys, int w, int h
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)w * h;
     int rc;
+    // one launch (a row per workgroup) where the row fits the LDS three times, else the three kernels
+    if (finish_pair_row_supported(w) && d_filled != d_occlusion)
+        return launch_finish_pair_row(p, d_keys, w, h, dminl, dminr, dOcclusion, vMin, d_best, d_dmap, d_occlusion,
+                                      d_filled, st);
     if ((rc = launch_finish_keys(d_keys, n, dminl, dminr, d_best, d_dmap, d_occlusion, st))) return rc;
     if ((rc = launch_detect_occlusion(p, d_occlusion, d_dmap + n, dOcclusion, w, h, st))) return rc;
     return launch_fill_occlusion(d_occlusion, d_filled, w, h, vMin, st);

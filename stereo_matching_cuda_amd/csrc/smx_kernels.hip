@@ -412,6 +412,113 @@ __global__ __launch_bounds__(64) void k_fill_occlusion(const float* in, float* d
     }
 }
 
+// main.cu:112-155 for one image row per workgroup, in one launch: presets + winning slice of each key of both
+// views (k_finish_keys), LR check of the left map (k_detect_occlusion; reads the right map only in its own row) and
+// filling (k_fill_occlusion: the same two ballot sweeps, by wave 0).  The three steps are pure selections on the
+// values of the row, so the results equal those of the three kernels.  All key loads of the row are in flight
+// before the first store.  Dynamic LDS: 3 w floats (left map -> occlusion row, right map, nearest-valid-at-left).
+constexpr int FP_NT = 256;
+constexpr int FP_MAXW = 8192;
+__global__ __launch_bounds__(FP_NT) void k_finish_pair_row(const int64_t* __restrict__ keys, int w, int h, int dminl,
+                                                            int dminr, int dOcclusion, int d_lr, float vMin,
+                                                            float* __restrict__ best, float* __restrict__ dmap,
+                                                            float* __restrict__ occlusion, float* __restrict__ filled) {
+    extern __shared__ float sbuf[];
+    float* sVal = sbuf;                      // left disparities of the row, then the row after the LR check
+    float* sR = sbuf + w;                    // right disparities of the row
+    float* sLeft = sbuf + 2 * w;
+    const int tid = threadIdx.x, y = blockIdx.x;
+    const int64_t n = (int64_t)w * h, r0 = (int64_t)y * w;
+    auto decode = [&](int64_t key, int dmin, float& b, float& d) {
+        b = __builtin_bit_cast(float, 0x7F7F7F7Fu);     // main.cu:112
+        d = 0.0f;                                        // main.cu:117
+        if (key != KEY_IDENTITY) {
+            float q;
+            uint32_t s;
+            unpack_key(key, &q, &s);
+            if (1.0f * b >= 1.0f * q) {                  // dispSelectOnGPU guidedFilter.cu:403-411
+                d = (float)(dmin + (int)s);
+                b = q;
+            }
+        }
+    };
+    for (int x0 = 0; x0 < w; x0 += 4 * FP_NT) {
+        int64_t kl[4], kr[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int x = min(x0 + t * FP_NT + tid, w - 1);
+            kl[t] = keys[r0 + x];
+            kr[t] = keys[n + r0 + x];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int x = x0 + t * FP_NT + tid;
+            if (x < w) {
+                float b, d;
+                decode(kl[t], dminl, b, d);
+                best[r0 + x] = b;
+                dmap[r0 + x] = d;
+                sVal[x] = d;
+                decode(kr[t], dminr, b, d);
+                best[n + r0 + x] = b;
+                dmap[n + r0 + x] = d;
+                sR[x] = d;
+            }
+        }
+    }
+    __syncthreads();
+    // detect_occlusionOnGPU occlusion.cu:3-15
+    for (int x = tid; x < w; x += FP_NT) {
+        float v = sVal[x];
+        const int d = (int)v;
+        if (x + d < 0 || x + d >= w || fabsf((float)d + sR[x + d]) > (float)d_lr) v = (float)dOcclusion;
+        sVal[x] = v;
+        occlusion[r0 + x] = v;
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    // fill_occlusionOnGPU1 occlusion.cu:134-176 (see k_fill_occlusion)
+    const int lane = tid;
+    float* out = filled + r0;
+    float carry = vMin;
+    for (int c0 = 0; c0 < w; c0 += 64) {
+        int x = c0 + lane;
+        float v = x < w ? sVal[x] : 0.0f;
+        bool valid = x < w && v >= vMin;
+        unsigned long long mask = __ballot(valid);
+        unsigned long long lower = mask & ((2ull << lane) - 1ull);
+        int src = lower ? 63 - __clzll((long long)lower) : lane;
+        float pick = __shfl(v, src);
+        if (x < w) sLeft[x] = lower ? pick : carry;
+        int last = mask ? 63 - __clzll((long long)mask) : 0;
+        float nv = __shfl(v, last);
+        if (mask) carry = nv;
+    }
+    carry = vMin;
+    for (int c0 = ((w - 1) / 64) * 64; c0 >= 0; c0 -= 64) {
+        int x = c0 + lane;
+        float v = x < w ? sVal[x] : 0.0f;
+        bool valid = x < w && v >= vMin;
+        unsigned long long mask = __ballot(valid);
+        unsigned long long upper = mask & (~0ull << lane);
+        int src = upper ? __ffsll((long long)upper) - 1 : lane;
+        float pick = __shfl(v, src);
+        float right = upper ? pick : carry;
+        if (x < w) {
+            int dX = (int)v;
+            if (!((float)dX >= vMin)) {
+                float l = sLeft[x];
+                out[x] = l > right ? l : right;
+            } else {
+                out[x] = v;
+            }
+        }
+        int first = mask ? __ffsll((long long)mask) - 1 : 0;
+        float nv = __shfl(v, first);
+        if (mask) carry = nv;
+    }
+}
+
 // =====================================================================================
 // filter()  (filter.cu:117-207; dead code in the reference: never called from main.cu)
 // Direct (2R+1)^2 box filter with zero padding, f32 accumulation in the reference's order (x offset
@@ -580,6 +687,19 @@ int launch_finish_keys(const int64_t* keys, int64_t n, int dminl, int dminr, flo
                        float* occlusion, hipStream_t st) {
     hipLaunchKernelGGL(k_finish_keys, dim3(cdiv(2 * n, 256)), dim3(256), 0, st, keys, n, dminl, dminr, best, dmap,
                        occlusion);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+// the three launches above as one (rows of up to FP_MAXW pixels; the caller falls back to the three kernels)
+bool finish_pair_row_supported(int w) { return w <= FP_MAXW; }
+int launch_finish_pair_row(const smx_params* p, const int64_t* keys, int w, int h, int dminl, int dminr, int dOcc,
+                           float vMin, float* best, float* dmap, float* occlusion, float* filled, hipStream_t st) {
+    const size_t lds = (size_t)w * 3 * sizeof(float);
+    if (lds > 64 * 1024)
+        SMX_HIP(hipFuncSetAttribute((const void*)k_finish_pair_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_finish_pair_row, dim3(h), dim3(FP_NT), lds, st, keys, w, h, dminl, dminr, dOcc, p->d_lr, vMin,
+                       best, dmap, occlusion, filled);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

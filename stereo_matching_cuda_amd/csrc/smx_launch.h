@@ -25,4 +25,7 @@ int launch_finish_keys(const int64_t* keys, int64_t n, int dminl, int dminr, flo
                        float* occlusion, hipStream_t st);
 int launch_filter(const smx_params* p, const uint8_t* I, uint8_t* mean, float* var, int w, int h,
                   hipStream_t st);
+bool finish_pair_row_supported(int w);
+int launch_finish_pair_row(const smx_params* p, const int64_t* keys, int w, int h, int dminl, int dminr, int dOcc,
+                           float vMin, float* best, float* dmap, float* occlusion, float* filled, hipStream_t st);
 }  // namespace smx

@@ -93,7 +93,7 @@ class PairPipeline:
 
     def finish(self):
         """Keys -> best/dmap (reference presets, dispSelect rule), LR check, filling: main.cu:112-155 in one
-        call (smx_dev_finish_pair: three launches)."""
+        call (smx_dev_finish_pair: one launch, a row per workgroup)."""
         with self._on_device():
             L, P, st = self.lib, C.byref(self.params), self._stream()
             _lib.check(L.smx_dev_finish_pair(P, _dp(self.keys), self.w, self.h, self.dminl, self.dminr,

@@ -150,8 +150,9 @@ def test_occlusion_tsukuba(tsukuba_oracle, golden):
     _eq(smx.write_mat(fil), golden["occlu_mapl_filled"], "filled png")
 
 
-@pytest.mark.parametrize("w,h", [(1, 3), (63, 4), (64, 4), (65, 4), (200, 5), (1242, 3)])
+@pytest.mark.parametrize("w,h", [(1, 3), (63, 4), (64, 4), (65, 4), (200, 5), (1242, 3), (8193, 3), (16384, 3)])
 def test_fill_occlusion_adversarial(orc, w, h):
+    """(rows of more than 8192 pixels need more than 64 KB of LDS: the launch raises the kernel's limit)"""
     rng = np.random.default_rng(w)
     vmin = -20.0
     d = rng.integers(-20, 1, size=(h, w)).astype(np.float32)
@@ -427,7 +428,7 @@ def test_pair_step_is_capturable_in_a_hip_graph(tsukuba_gray, tsukuba_oracle):
 
 
 def test_finish_pair_equals_the_per_call_sequence(tsukuba_gray, tsukuba_oracle):
-    """smx_dev_finish_pair (three launches) against smx_dev_init_wta + 2 x smx_dev_apply_keys + copy +
+    """smx_dev_finish_pair (one launch) against smx_dev_init_wta + 2 x smx_dev_apply_keys + copy +
     smx_dev_detect_occlusion + copy + smx_dev_fill_occlusion, and both against the oracle."""
     import torch
     from stereo_matching_cuda_amd.device import PairPipeline
@@ -444,6 +445,42 @@ def test_finish_pair_equals_the_per_call_sequence(tsukuba_gray, tsukuba_oracle):
     for k in ("dmapl", "dmapr", "bestl", "bestr", "occlusion", "filled"):
         _eq(fused[k], percall[k], k)
         _eq(fused[k], tsukuba_oracle[k], k)
+
+
+@pytest.mark.parametrize("w,h,D", [(1242, 5, 9), (300, 7, 3), (8192, 3, 5), (9000, 3, 5)])
+def test_finish_pair_on_random_keys(orc, w, h, D):
+    """smx_dev_finish_pair on keys that no aggregation produced (random costs and slices, some pixels without any
+    candidate): the one-launch form (rows <= 8192 pixels) and the three-kernel form behind it, against the oracle's
+    presets / dispSelect rule / LR check / filling."""
+    import torch
+    from stereo_matching_cuda_amd.device import PairPipeline
+    rng = np.random.default_rng(w + h)
+    dminl, dminr = -(D - 1), 0
+    cost = (rng.random((2, h, w), dtype=np.float32) * 3).astype(np.float32)
+    cost[rng.random((2, h, w)) < 0.05] = np.nan           # -> identity keys: the presets survive
+    slices = rng.integers(0, D, size=(2, h, w))
+    keys = orc.pack_keys(cost, slices)
+    pipe = PairPipeline(w, h, D, dminl=dminl, dminr=dminr)
+    pipe.keys.copy_(torch.from_numpy(keys.reshape(2, h, w)))
+    pipe.finish()
+    torch.cuda.synchronize()
+    got = {k: getattr(pipe, k).cpu().numpy() for k in ("best", "dmap", "occlusion", "filled")}
+    has = ~np.isnan(cost)
+    best = np.where(has, cost, np.float32(np.frombuffer(b"\x7f\x7f\x7f\x7f", np.float32)[0])).astype(np.float32)
+    dmin = np.array([dminl, dminr]).reshape(2, 1, 1)
+    dmap = np.where(has, (dmin + slices).astype(np.float32), np.float32(0)).astype(np.float32)
+    _eq(got["best"], best, "best")
+    _eq(got["dmap"], dmap, "dmap")
+    occ = orc.detect_occlusion(dmap[0], dmap[1], dminl - 100)
+    _eq(got["occlusion"], occ, "occlusion")
+    _eq(got["filled"], orc.fill_occlusion(occ, float(dminl)), "filled")
+    # and the per-call sequence on the same keys
+    for t in (pipe.best, pipe.dmap, pipe.occlusion, pipe.filled):
+        t.fill_(-7.0)
+    pipe.finish_per_call()
+    torch.cuda.synchronize()
+    for k in got:
+        _eq(getattr(pipe, k).cpu().numpy(), got[k], "per-call " + k)
 
 
 def test_two_pipelines_on_two_devices(tsukuba_gray, tsukuba_oracle):
