@@ -134,6 +134,7 @@ __device__ __forceinline__ bool div_needs_exact(float x) {
 // guidedFilter.cu:209).  The halves convert exactly, so the f32 operations equal the reference's; the
 // sentinel 60000 of an out-of-range partner saturates both terms = the border constant (:184).
 __device__ __forceinline__ f2 cost_pair(fg_t q1, fg_t q2, const CostConst& cc) {
+#ifdef SMX_V4_COST_SCALAR
     const float a1 = (float)q1.x, b1 = (float)q1.y, a2 = (float)q2.x, b2 = (float)q2.y;
     float t1 = fabsf(a1 - a2);
     float t2 = fabsf(b1 - b2);
@@ -145,12 +146,24 @@ __device__ __forceinline__ f2 cost_pair(fg_t q1, fg_t q2, const CostConst& cc) {
     r.x = x + z;
     r.y = a1 * r.x;
     return r;
+#else
+    // the same operations, the two differences and the two products as packed instructions, the two selects as
+    // v_min_f32 (no operand is ever a NaN: the inputs are finite halves, so min(|d|, th) == (|d| < th ? |d| : th))
+    const f2 v1 = {(float)q1.x, (float)q1.y}, v2 = {(float)q2.x, (float)q2.y};
+    const f2 d = v1 - v2;
+    const f2 m = {__builtin_fminf(__builtin_fabsf(d.x), cc.th_color), __builtin_fminf(__builtin_fabsf(d.y), cc.th_grad)};
+    const f2 xz = (f2){cc.oma, cc.alpha} * m;
+    f2 r;
+    r.x = xz.x + xz.y;
+    r.y = v1.x * r.x;
+    return r;
+#endif
 }
 
 // ---- hand-off accesses: sc1 (bypass this CU's L1, write through the XCD's L2) ----------------
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int AUX_SC1 = 16;
-constexpr int AUX_NT = 2;
+constexpr int AUX_NT = 2;   // q stores and the WTA's q loads are nt: measured best of plain / sc1 / nt
 __device__ __forceinline__ rsrc_t mk_rsrc(const void* p, size_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0,
                                              (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes),
@@ -569,8 +582,30 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
             return g;
         };
         auto coloff = [&](int x) { return x >= 0 && x < w ? (unsigned)x * 4u : OOB; };
-        auto vg_of = [&]() { return coloff(xs + opaque(lane)); };        // a_k, b_k column
-        auto vq_of = [&]() { return coloff(xs - R + opaque(lane)); };    // q column
+        // Per-lane constants of the item that every iteration needs stay in VGPRs (the kernel has 80 to spend at three
+        // workgroups per CU): re-deriving them costs more vector instructions than anything else they could buy.
+        const unsigned vg_keep = coloff(xs + lane), vq_keep = coloff(xs - R + lane);
+        auto vg_of = [&]() { return vg_keep; };                          // a_k, b_k column
+        auto vq_of = [&]() { return vq_keep; };                          // q column
+        // the hand-off unit of this thread: byte offset inside a record; ring-2 float offset of its (row, column)
+        // relative to the first row of the band; which of its two columns lie inside the halo
+        const unsigned rec_voff = wave < NRSW ? (unsigned)(((sstage_of() * BH + srow_of()) * 8) & ~15)
+                                              : ((hu_halo || hu_carry) ? hu_off() : 0u);
+        int hu_r0, hu_c0;
+        hu_rc(hu_r0, hu_c0);
+        const int hu_lds = hu_r0 * ROWF + hu_c0;
+        const bool hu_in = hu_c0 < HW, hu_two = hu_c0 + 1 < HW;
+        // ring float offset of row (rbase + r) for a kept offset o = r * ROWF + c (c + 64 < ROWF)
+        auto ring_off = [&](int rbase, int o) {
+            const int v = rbase * ROWF + o;
+            return v >= RR * ROWF ? v - RR * ROWF : v;
+        };
+        // the stage-1 quad of this thread: ring-1 offset, byte offsets in the two input planes (without the band term)
+        int q_r0, q_c0;
+        quad_rc(0, q_r0, q_c0);
+        const int q_lds = q_r0 * ROWF + q_c0;
+        const unsigned q_off1 = (unsigned)(min(max(cs1 + q_c0, -PADX), w) + PADX) * 4u + (unsigned)q_r0 * fgw4;
+        const unsigned q_off2 = (unsigned)(min(max(cs1 + q_c0 + d, -PADX), w) + PADX) * 4u + (unsigned)q_r0 * fgw4;
         // all 64 windows of the strip unclipped in x: no selects, one area
         const bool xint1 = xs - R - 1 >= 0 && xs + OW - 1 + R <= w - 1;
         const bool xint2 = xs - 2 * R - 1 >= 0 && xs + OW - 1 <= w - 1;
@@ -596,6 +631,20 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
         // loads of the stage-1 inputs of band ib (rows clamped into the image: every load is issued)
         auto issue_cost = [&](int ib) {
             if (!q_on) return;
+            if (SRC == SRC_IMG && NQR == 1) {
+                // kept per-lane offsets + the band's row offset as the scalar operand; the rows of the last band are
+                // clamped per lane.  (One load site: loads in two branches would be waited for where they merge.)
+                unsigned vo1 = q_off1, vo2 = q_off2;
+                int soff = BH * ib * (int)fgw4;
+                if (BH * ib + BH > h) {
+                    const unsigned dy = (unsigned)(BH * ib + q_r0 - min(BH * ib + q_r0, h - 1)) * fgw4;
+                    vo1 -= dy;
+                    vo2 -= dy;
+                }
+                qa[0] = __builtin_amdgcn_raw_buffer_load_b128(r_fg1, (int)vo1, soff, 0);
+                qb[0] = __builtin_amdgcn_raw_buffer_load_b128(r_in2, (int)vo2, soff, 0);
+                return;
+            }
 #pragma unroll
             for (int e = 0; e < NQR; ++e) {
                 int qr, qc;
@@ -665,9 +714,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
         // new register values right behind it, i.e. wait for it on the spot): the halo unit of a thread of waves
         // QW0.., the unit that holds its carry for a row-scan lane (any unit for the others: never used).
         auto fetch_rec = [&](int rec) {
-            const unsigned base = (unsigned)(rec * REC_F2 * 8);
-            const unsigned coff = (unsigned)(((sstage_of() * BH + srow_of()) * 8) & ~15);
-            hreg = ld16_sc1(r_in, base + (wave < NRSW ? coff : (hu_halo ? hu_off() : 0u)));
+            hreg = ld16_sc1(r_in, (unsigned)(rec * REC_F2 * 8) + rec_voff);
         };
         // bounded wait for the left neighbour's flag >= need (thread 0 only); result -> s_seen
         auto spin_pred = [&](unsigned need) {
@@ -1017,11 +1064,16 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                 if (q_on) {
 #pragma unroll
                     for (int e = 0; e < NQR; ++e) {
-                        int qr, qc;
-                        quad_rc(e, qr, qc);
-                        int rw = rb + qr;
-                        rw = rw >= RR ? rw - RR : rw;
-                        float* dst = ring1 + rw * ROWF + qc;
+                        float* dst;
+                        if (NQR == 1) {
+                            dst = ring1 + ring_off(rb, q_lds);
+                        } else {
+                            int qr, qc;
+                            quad_rc(e, qr, qc);
+                            int rw = rb + qr;
+                            rw = rw >= RR ? rw - RR : rw;
+                            dst = ring1 + rw * ROWF + qc;
+                        }
                         *(f4*)dst = (f4){qres[e][0].x, qres[e][1].x, qres[e][2].x, qres[e][3].x};
                         *(f4*)(dst + OFF1) = (f4){qres[e][0].y, qres[e][1].y, qres[e][2].y, qres[e][3].y};
                     }
@@ -1074,14 +1126,10 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                 if (!(WHATIF & 4)) eval_cost();
                 // the left neighbour's last 2R+1 columns of the stage-2 integral of band i-1 -> ring 2 (nobody
                 // touches these columns before X(i))
-                int hu_r, hu_c;
-                hu_rc(hu_r, hu_c);
-                if (pred && hu_halo && i >= 1 && hu_c < HW) {
-                    int rr = rbp + hu_r;
-                    rr = rr >= RR ? rr - RR : rr;
+                if (pred && hu_halo && i >= 1 && hu_in) {
                     // unit = (first, second) component of column hu_c, then of column hu_c + 1
-                    float* dst = ring2 + rr * ROWF + hu_c;
-                    if (hu_c + 1 < HW) {
+                    float* dst = ring2 + ring_off(rbp, hu_lds);
+                    if (hu_two) {
                         *(f2*)dst = (f2){hreg.x, hreg.z};
                         *(f2*)(dst + OFF1) = (f2){hreg.y, hreg.w};
                     } else {
@@ -1188,15 +1236,11 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                 if (hu_carry) {
                     hov = *(const f4*)(&cout[0][0] + 2 * (qt - NHALO_U));   // cout[0][0 .. BH), cout[1][0 .. BH) are contiguous
                 } else {
-                    int hu_r, hu_c;
-                    hu_rc(hu_r, hu_c);
-                    int rr = rbp + hu_r;
-                    rr = rr >= RR ? rr - RR : rr;
-                    const float* p = ring2 + rr * ROWF + OW + hu_c;
+                    const float* p = ring2 + ring_off(rbp, hu_lds + OW);
                     const f2 a = *(const f2*)p, b = *(const f2*)(p + OFF1);
                     hov = (f4){a.x, b.x, a.y, b.y};
                 }
-                st16_sc1(r_out, (unsigned)((i * REC_F2) * 8) + hu_off(), hov);
+                st16_sc1(r_out, (unsigned)((i * REC_F2) * 8) + rec_voff, hov);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!(WHATIF & 1)) issue_guid(i + 1);      // (rows are clamped into the image: harmless behind the last iteration)

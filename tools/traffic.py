@@ -6,7 +6,7 @@ pmc_WRITE_SIZE) into the HBM-traffic figure bench.py reports as roofline.traffic
 
 Per MI355X_MICROARCH.md (HBM / rocprofv3): FETCH_SIZE and WRITE_SIZE come from separate --pmc passes
 and are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of a coalesced stream.  The x2 is
-checked here on k_v3_wta, which reads the aggregated volumes exactly once (known byte count: the
+checked here on k_v4_wta2 / k_v3_wta, which read the aggregated volumes exactly once (known byte count: the
 bench's 2 x 1242 x 375 x 192 floats + the key planes)."""
 import collections
 import csv
@@ -14,7 +14,7 @@ import glob
 import json
 import sys
 
-AGG_KERNELS = ("k_v3_walk", "k_v3_wta", "k_v3_prep")
+AGG_KERNELS = ("k_v3_", "k_v4_")      # every kernel of the fused aggregation call (either kernel generation)
 
 
 def main(src, dst=None):
@@ -38,7 +38,7 @@ def main(src, dst=None):
         "source": src,
         "method": "sum over the kernels of one smx_dev_aggregate_wta_pair call of "
                   "(2*FETCH_SIZE + WRITE_SIZE)*1024 per dispatch; FETCH_SIZE x2 = gfx950 correction "
-                  "(MI355X_MICROARCH.md), checked on k_v3_wta (reads q exactly once)",
+                  "(MI355X_MICROARCH.md), checked on the WTA kernel (reads q exactly once)",
         "aggregation_call_hbm_bytes": sum(per[k]["hbm_bytes"] for k in agg),
         "kernels": {k: per[k] for k in sorted(per)},
     }
