@@ -617,7 +617,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
         // stage-1 inputs of the next band: raw quads (four (value, gradient) cells of this view / of the other view,
         // or four raw costs), loaded in W(i); evaluated to (p, I p) under the row scans of R(i); written in W(i+1)
         u4 qa[NQR], qb[NQR];
-        f2 qres[NQR][4];
+        f4 qresx[NQR], qresy[NQR];          // (p, I p) of the quad, planar like the ring rows they are written to
         f2 gab[RPW];                         // (mean_I, 1/(var+eps)) of the a/b rows of the next X phase
         uint32_t Iraw[RPW];                  // raw (value, gradient) halves of the q rows of the next X phase
         f2 abreg[RPW];                       // a_k, b_k of this wave's rows, written to ring 2 in the next W phase
@@ -685,7 +685,8 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                         v.x = __builtin_bit_cast(float, rb4[j]);   // copyFromBigToLittleOnGPU guidedFilter.cu:198
                         v.y = (float)q1.x * v.x;                   // pixelMultOnGPU(d_im, d_p) :209
                     }
-                    qres[e][j] = v;
+                    qresx[e][j] = v.x;
+                    qresy[e][j] = v.y;
                 }
             }
         };
@@ -967,7 +968,6 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                     }
                 }
             }
-            float amin = __builtin_inff(), amax = 0.0f;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f2 v = s11[t] - s10[t];
@@ -975,9 +975,10 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                 v = v + s00[t];
                 val[t] = v;
                 m[t] = (WHATIF & 256) ? v : div_small_int2(v, area_full, ra_full);
-                amin = fminf(amin, fminf(fabsf(v.x), fabsf(v.y)));
-                amax = fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y)));
             }
+            // smallest / largest magnitude of the four sums: v_min3 + v_min, v_max3 + v_max
+            const float amin = fminf(fminf(fminf(fabsf(val[0].x), fabsf(val[0].y)), fabsf(val[1].x)), fabsf(val[1].y));
+            const float amax = fmaxf(fmaxf(fmaxf(fabsf(val[0].x), fabsf(val[0].y)), fabsf(val[1].x)), fabsf(val[1].y));
             // tiny, zero, infinite window sums (a NaN sum gives a NaN mean on either path)
             if (!(WHATIF & 128) && __any(!(amin >= 0x1p-100f) || !(amax < __builtin_inff()))) {
                 asm volatile("; exact-division slow path");   // keep this a real (rare) wave-uniform branch
@@ -1074,8 +1075,8 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                             rw = rw >= RR ? rw - RR : rw;
                             dst = ring1 + rw * ROWF + qc;
                         }
-                        *(f4*)dst = (f4){qres[e][0].x, qres[e][1].x, qres[e][2].x, qres[e][3].x};
-                        *(f4*)(dst + OFF1) = (f4){qres[e][0].y, qres[e][1].y, qres[e][2].y, qres[e][3].y};
+                        *(f4*)dst = qresx[e];
+                        *(f4*)(dst + OFF1) = qresy[e];
                     }
                 }
                 if (i >= 1) {
