@@ -3,11 +3,11 @@
 // leaving the CU.  Reference: guidedFilter.cu:171-238, costVolume.cu:163-190, integral.cu:78-131.
 //
 // Work item = (slice-view sv, strip k): a column strip of OW = 64 output columns, walked top -> bottom in
-// bands of BH = 32 rows by one 512-thread workgroup.  TWO workgroups share a CU (72 KB of LDS each): while
-// one of them sits in a latency-bound phase (the sequential scans) the other one fills the SIMDs, which is
-// what the one-workgroup-per-CU predecessor (smx_agg_v3.hip) could not do.  Two LDS rings of 52 rows x 83
-// columns of float2 hold the integral images of stage 1 (p, I*p) and stage 2 (a, b): a band of box means
-// needs BH + 2R + 1 rows.
+// bands of BH = 16 rows by one 512-thread workgroup.  THREE workgroups share a CU (49.5 KB of LDS, <= 80 VGPRs
+// each): while one of them sits in a latency-bound phase (the sequential scans) the others fill the SIMDs, which
+// is what the one-workgroup-per-CU predecessor (smx_agg_v3.hip) could not do.  Two LDS rings of RR = 36 rows x 83
+// columns x 2 components hold the integral images of stage 1 (p, I*p) and stage 2 (a, b): a band of box means
+// needs BH + 2R + 1 rows.  (BH = 32 with two workgroups per CU also builds: -DSMX_V4_BH=32, 3 % slower.)
 //
 // Exactness: every prefix sum keeps the reference's order (sequential left -> right in a row, then
 // sequential top -> bottom in a column; integral.cu:82-86, 124-128), the box mean its tap order
@@ -16,15 +16,19 @@
 // columns it shares with its left neighbour; stage 2 lags stage 1 by R rows and R columns and receives the
 // 2R+1 finished integral columns it shares with its left neighbour from that neighbour (hand-off record).
 //
-// Iteration i of an item (four workgroup barriers):
-//   W(i)  all waves: cost of band i (loaded in X(i-1)) -> ring 1; a_k, b_k of band i-1 (computed in X(i-1))
-//         -> ring 2; the left neighbour's record i -> LDS (row carries, stage-2 halo columns)
-//   R(i)  wave 0: row scan of stage 1, band i | wave 1: row scan of stage 2, band i-1   (LANE = ROW x component)
-//   C(i)  waves 0, 1: column scan of stage 1, band i | wave 2: column scan of stage 2, band i-1 (LANE = COLUMN)
-//   X(i)  all waves, LANE = COLUMN, 4 rows each: record i -> global; box means of stage 2 -> q rows of band
-//         i-1 (lagged by 2R) -> HBM; box means of stage 1 -> a_k, b_k of band i (lagged by R, registers);
-//         loads for iteration i+1
-// Every global access is a row-major 256-byte run issued as a buffer instruction.
+// Iteration i of an item (four workgroup barriers, each ordering LDS only):
+//   W(i)  waves 2..7: (p, I p) of band i (loaded in W(i-1), evaluated in R(i-1)) -> ring 1; all waves: a_k, b_k
+//         of band i-1 (computed in X(i-1)) -> ring 2; loads of the stage-1 inputs of band i+1
+//   R(i)  wave 0: row scans of stage 1 (band i) and stage 2 (band i-1), lane = (stage, row, component), four
+//         columns per LDS instruction | waves 2..7: evaluate band i+1's costs, the left neighbour's stage-2 halo
+//         columns (record i, loaded in X(i-1)) -> ring 2, drain of the record stores of X(i-1)
+//   C(i)  waves 0..2: column scan of stage 1, band i | waves 3, 4: column scan of stage 2, band i-1
+//         (lane = one dword of a ring row, running sums in registers down the strip); one lane publishes record i-1
+//   X(i)  all waves, LANE = COLUMN, 2 rows each: box means of stage 1 -> a_k, b_k of band i (lagged by R,
+//         registers); box means of stage 2 -> q rows of band i-1 (lagged by 2R) -> HBM; record i -> global;
+//         load of the neighbour's record i+1; guidance loads for X(i+1)
+// Every global access is a row-major run issued as a buffer instruction (per-lane byte offset kept in a VGPR for the
+// whole item + scalar row offset).
 //
 // Items are handed out by a ticket counter in strip-major order, so the left neighbour of an item always
 // holds an earlier ticket (it is running or done: no deadlock whatever the dispatch order).  The hand-off is

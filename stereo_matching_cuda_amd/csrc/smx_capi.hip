@@ -93,7 +93,7 @@ void smx_default_params(smx_params* p) {
 
 const char* smx_last_error(void) { return g_err.c_str(); }
 
-const char* smx_version(void) { return "smx-hip gfx950 0.3 (single-kernel fused guided-filter aggregation)"; }
+const char* smx_version(void) { return "smx-hip gfx950 0.4 (fused guided-filter aggregation, three workgroups per CU)"; }
 
 int smx_device_count(void) {
     int n = 0;
