@@ -614,6 +614,12 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
         const bool xint1 = xs - R - 1 >= 0 && xs + OW - 1 + R <= w - 1;
         const bool xint2 = xs - 2 * R - 1 >= 0 && xs + OW - 1 <= w - 1;
         const float area_full = (float)(HW * HW), ra_full = rcp_s[HW * HW];
+        // iterations whose box stage is interior (every window of the band unclipped): [f_lo, f_lo + f_n)
+        //   stage 1, band i:   BH i - 2R - 1 >= 0 and BH i + BH <= h
+        //   stage 2, band i-1: BH (i-1) - 3R - 1 >= 0 and BH i - R <= h
+        const int f1_lo = (2 * R + 1 + BH - 1) / BH, f2_lo = 1 + (3 * R + 1 + BH - 1) / BH;
+        const unsigned f1_n = xint1 ? (unsigned)max(h / BH - f1_lo, 0) : 0u;
+        const unsigned f2_n = xint2 ? (unsigned)max((h + R) / BH - f2_lo + 1, 0) : 0u;
 
         const int jlo1 = max(0, -cs1), jhi1 = min(TW, w - cs1);   // ring-1 columns inside the image
         const int jlo2 = HW, jhi2 = min(TW, w - cs2);             // new ring-2 columns inside the image
@@ -937,18 +943,20 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
         // bottom tap row (the top tap row is 2R+1 ring rows above it).
         // a cell's (first, second) component: one ds_read2_b32
         auto cell = [&](const float* p) { return (f2){p[0], p[OFF1]}; };
-        auto box2_fast = [&](const float* ring, int rbase, int half, f2* m) {
-            int rb0 = rbase + RPW * wave;
-            rb0 = rb0 >= RR ? rb0 - RR : rb0;            // the wave's group of RPW bottom rows never wraps
-            rb0 += 2 * half;
+        // obf = ring float offset of the wave's first bottom tap row (its group of RPW rows never wraps)
+        auto box2_fast = [&](const float* ring, int obf, int half, f2* m) {
+            const int ob0 = obf + 2 * half * ROWF;
             f2 s11[2], s10[2], s01[2], s00[2], val[2];
             if (RT == RMAX && !(WHATIF & 2)) {
                 static_assert(HWMAX + OFF1 < 256, "ds_read2_b32 offsets");
+                // top tap rows: HW ring rows above, each wrapped on its own
+                int ot0 = ob0 - HW * ROWF;
+                ot0 = ot0 < 0 ? ot0 + RR * ROWF : ot0;
+                int ot1 = ot0 + ROWF;
+                ot1 = ot1 >= RR * ROWF ? ot1 - RR * ROWF : ot1;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    int rt = rb0 + t - HW;
-                    rt = rt < 0 ? rt + RR : rt;
-                    const unsigned ab = lds_off(ring + (rb0 + t) * ROWF + lane), at = lds_off(ring + rt * ROWF + lane);
+                    const unsigned ab = lds_off(ring + ob0 + t * ROWF + lane), at = lds_off(ring + (t ? ot1 : ot0) + lane);
                     LDS_RD2(s11[t], ab, HWMAX, HWMAX + OFF1);
                     LDS_RD2(s10[t], ab, 0, OFF1);
                     LDS_RD2(s01[t], at, HWMAX, HWMAX + OFF1);
@@ -960,25 +968,32 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
             } else {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    int rt = rb0 + t - HW;
-                    rt = rt < 0 ? rt + RR : rt;
-                    const float* pb = ring + (rb0 + t) * ROWF + lane;
-                    const float* pt = ring + rt * ROWF + lane;
+                    int ot = ob0 + (t - HW) * ROWF;
+                    ot = ot < 0 ? ot + RR * ROWF : ot;
+                    const float* pb = ring + ob0 + t * ROWF + lane;
+                    const float* pt = ring + ot + lane;
                     if (WHATIF & 2) {
-                        s11[t] = s10[t] = s01[t] = s00[t] = (f2){(float)(rb0 + lane), 2.0f + rt};
+                        s11[t] = s10[t] = s01[t] = s00[t] = (f2){(float)(ob0 + lane), 2.0f + ot};
                     } else {
                         s11[t] = cell(pb + HW); s10[t] = cell(pb);
                         s01[t] = cell(pt + HW); s00[t] = cell(pt);
                     }
                 }
             }
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f2 v = s11[t] - s10[t];
-                v = v - s01[t];
-                v = v + s00[t];
-                val[t] = v;
-                m[t] = (WHATIF & 256) ? v : div_small_int2(v, area_full, ra_full);
+            // (the two rows' dependent chains interleaved: a packed instruction that reads the result of the one in
+            // front of it costs a wait state)
+            f2 v0 = s11[0] - s10[0], v1 = s11[1] - s10[1];
+            v0 = v0 - s01[0]; v1 = v1 - s01[1];
+            v0 = v0 + s00[0]; v1 = v1 + s00[1];
+            val[0] = v0; val[1] = v1;
+            if (WHATIF & 256) {
+                m[0] = v0; m[1] = v1;
+            } else {
+                const f2 d2 = {area_full, area_full}, r2 = {ra_full, ra_full};
+                f2 q0 = v0 * r2, q1 = v1 * r2;
+                f2 e0 = __builtin_elementwise_fma(-q0, d2, v0), e1 = __builtin_elementwise_fma(-q1, d2, v1);
+                m[0] = __builtin_elementwise_fma(e0, r2, q0);
+                m[1] = __builtin_elementwise_fma(e1, r2, q1);
             }
             // smallest / largest magnitude of the four sums: v_min3 + v_min, v_max3 + v_max
             const float amin = fminf(fminf(fminf(fabsf(val[0].x), fabsf(val[0].y)), fabsf(val[1].x)), fabsf(val[1].y));
@@ -993,9 +1008,9 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                 }
             }
         };
-        auto box4_fast = [&](const float* ring, int rbase, f2 (&m)[RPW]) {
+        auto box4_fast = [&](const float* ring, int obf, f2 (&m)[RPW]) {
 #pragma unroll
-            for (int hf = 0; hf < RPW / 2; ++hf) box2_fast(ring, rbase, hf, &m[2 * hf]);
+            for (int hf = 0; hf < RPW / 2; ++hf) box2_fast(ring, obf, hf, &m[2 * hf]);
         };
         // general form: windows clipped at the image borders; rows y0 + t that do not exist are skipped
         // (ok[t] = false).  shift = 0 (ring 1) or R (ring 2).
@@ -1037,14 +1052,23 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
         // q rows of X(iq)
         float qout[RPW];
         bool qok[RPW];
-        auto store_q = [&](int iq) {
+        // (interior: every row exists and every lane's column is its own -- no predicate, no clamp)
+        auto store_q = [&](int iq, bool interior) {
             if (WHATIF & 1) return;
             const unsigned vq = vq_of();
             const int yq0 = BH * (iq - 1) - 2 * R + RPW * wave;
+            unsigned vo[RPW];
+            int so[RPW];
+            if (interior) {
+#pragma unroll
+                for (int t = 0; t < RPW; ++t) { vo[t] = vq; so[t] = (yq0 + t) * (int)w4; }
+            } else {
+#pragma unroll
+                for (int t = 0; t < RPW; ++t) { vo[t] = qok[t] ? vq : OOB; so[t] = min(max(yq0 + t, 0), h - 1) * (int)w4; }
+            }
 #pragma unroll
             for (int t = 0; t < RPW; ++t)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qout[t]), r_q, (int)(qok[t] ? vq : OOB),
-                                                      min(max(yq0 + t, 0), h - 1) * (int)w4, AUX_NT);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qout[t]), r_q, (int)vo[t], so[t], AUX_NT);
         };
 
         // ===================================== the band loop ==============================================
@@ -1062,6 +1086,8 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
         eval_cost();
         float Sc = -0.0f;                   // running column sum of this lane's dword (waves 0..4)
         int rb = 0, rbp = 0;                // ring row of the first row of band i / band i-1 (both rings)
+        // ring float offset of this wave's group of RPW rows of band i / band i-1 (a group never wraps)
+        int ob1 = RPW * wave * ROWF, ob2 = ob1;
         for (int i = 0; i < NI; ++i) {
             // ------------------------------------ W(i) --------------------------------------------------
             V4_STAMP(0);
@@ -1084,11 +1110,9 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                     }
                 }
                 if (i >= 1) {
-                    int rw2 = rbp + RPW * wave;
-                    rw2 = rw2 >= RR ? rw2 - RR : rw2;
 #pragma unroll
                     for (int t = 0; t < RPW; ++t) {
-                        float* dst = ring2 + (rw2 + t) * ROWF + HW + lane;
+                        float* dst = ring2 + ob2 + t * ROWF + HW + lane;
                         dst[0] = abreg[t].x;
                         dst[OFF1] = abreg[t].y;
                     }
@@ -1172,6 +1196,22 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
             // ------------------------------------ X(i) --------------------------------------------------
             seen = s_seen;
             V4_STAMP(8);
+#ifdef SMX_V4_EXTRA_SALU
+            {   // sensitivity experiment: SMX_V4_EXTRA_SALU dependent scalar adds per wave and iteration
+                int dummy = i;
+#pragma unroll
+                for (int z = 0; z < SMX_V4_EXTRA_SALU; ++z) asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy));
+                asm volatile("" :: "s"(dummy));
+            }
+#endif
+#ifdef SMX_V4_EXTRA_VALU
+            {
+                int dummy = lane;
+#pragma unroll
+                for (int z = 0; z < SMX_V4_EXTRA_VALU; ++z) asm volatile("v_add_u32 %0, %0, 1" : "+v"(dummy));
+                asm volatile("" :: "v"(dummy));
+            }
+#endif
             // Order of the phase: everything that consumes a value loaded in the previous iteration comes before
             // the first global access of this one.  (The compiler cannot count loads across the loop edge: the
             // first such use behind a new access waits for ALL outstanding accesses, the new one included.)
@@ -1193,8 +1233,8 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
                 if (WHATIF & (64 | 512)) {
 #pragma unroll
                     for (int t = 0; t < RPW; ++t) m[t] = (f2){1.0f + lane, 2.0f};
-                } else if (xint1 && BH * i - 2 * R - 1 >= 0 && BH * i + BH <= h) {
-                    box4_fast(ring1, rb, m);
+                } else if ((unsigned)(i - f1_lo) < f1_n) {
+                    box4_fast(ring1, ob1, m);
                 } else {
                     box4_gen(ring1, 0, mkgeo(xs + opaque(lane), cs1), xint1, ya0, m, ok);
                 }
@@ -1211,14 +1251,15 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
             const int yq0 = BH * (i - 1) - 2 * R + RPW * wave;
 #pragma unroll
             for (int t = 0; t < RPW; ++t) { qout[t] = 0.0f; qok[t] = false; }
+            const bool fast2 = (unsigned)(i - f2_lo) < f2_n;
             if (i >= 1) {
                 // box means of stage 2 -> q rows [BH (i-1) - 2R, BH i - 2R)
                 f2 m[RPW];
                 if (WHATIF & (64 | 1024)) {
 #pragma unroll
                     for (int t = 0; t < RPW; ++t) m[t] = (f2){1.0f + lane, 2.0f};
-                } else if (xint2 && BH * (i - 1) - 3 * R - 1 >= 0 && BH * i - R <= h) {
-                    box4_fast(ring2, rbp, m);
+                } else if (fast2) {
+                    box4_fast(ring2, ob2, m);
 #pragma unroll
                     for (int t = 0; t < RPW; ++t) qok[t] = true;
                 } else {
@@ -1234,7 +1275,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
             V4_STAMP(10);
             __builtin_amdgcn_sched_barrier(0);
             // ---- the global accesses of the phase: q rows, record i, the loads of iteration i+1 ----
-            if (i >= 1) store_q(i);
+            if (i >= 1) store_q(i, fast2 && !(WHATIF & (64 | 1024)));
             if (succ && (hu_halo || hu_carry)) {
                 // record i: row carries of this iteration's row scans, last 2R+1 columns of the stage-2 integral
                 f4 hov;
@@ -1254,6 +1295,9 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
             rbp = rb;
             rb += BH;
             rb = rb >= RR ? rb - RR : rb;
+            ob2 = ob1;
+            ob1 += BH * ROWF;
+            ob1 = ob1 >= RR * ROWF ? ob1 - RR * ROWF : ob1;
         }
         // the last record and the last q rows: drained, then published
         drain_vmem();
