@@ -166,7 +166,8 @@ size_t smx_agg_workspace_bytes(int w, int h, int nslices);
  *              signed 64-bit integers (sord = order-preserving f32 -> i32 map); initialise with
  *              smx_dev_init_keys (INT64_MAX); combine across shards with an int64 MIN all-reduce
  *   d_mean_u8: optional u8 mean image out (guidedFilter.cu:87,122)
- *   d_agg    : optional aggregated slices out, slice s at d_agg[(s - s_begin)*w*h]
+ *   d_agg    : optional aggregated slices out, slice s at d_agg[(s - s_begin)*w*h]; any 4-byte aligned pointer
+ *              (the WTA pass reads it with 8-byte loads when it is 8-byte aligned and w*h is even, else with 4-byte ones)
  * Slices are processed in chunks that fit the workspace (>= smx_agg_workspace_bytes(w,h,1)). */
 int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uint8_t* d_other,
                           const float* d_cost, int w, int h, int dmin, int s_begin, int s_end,

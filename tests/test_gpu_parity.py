@@ -447,6 +447,24 @@ def test_finish_pair_equals_the_per_call_sequence(tsukuba_gray, tsukuba_oracle):
         _eq(fused[k], tsukuba_oracle[k], k)
 
 
+def test_aggregated_volume_out_at_a_4_byte_aligned_address(orc):
+    """d_agg needs no more than float alignment: with an even plane size the WTA pass reads q with 8-byte loads
+    only if the address allows it (include/smx.h)."""
+    import torch
+    from stereo_matching_cuda_amd.device import PairPipeline
+    w, h, D = 150, 100, 4
+    Il, Ir = synth.gen_pair(w, h, D, 5)
+    want = orc.stereo_pair(Il, Ir, D, want_agg=True)
+    pipe = PairPipeline(w, h, D, want_agg=True)
+    buf = torch.empty(2 * D * h * w + 1, dtype=torch.float32, device="cuda")
+    pipe.agg = buf[1:].view(2, D, h, w)
+    assert pipe.agg.data_ptr() % 8 == 4
+    pipe.run(torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda())
+    got = pipe.results()
+    for k in ("aggl", "aggr", "dmapl", "dmapr", "bestl", "bestr", "filled"):
+        _eq(got[k], want[k], k)
+
+
 @pytest.mark.parametrize("w,h,D", [(1242, 5, 9), (300, 7, 3), (8192, 3, 5), (9000, 3, 5)])
 def test_finish_pair_on_random_keys(orc, w, h, D):
     """smx_dev_finish_pair on keys that no aggregation produced (random costs and slices, some pixels without any
