@@ -132,6 +132,21 @@ def _stage_tsukuba(tmp_path):
 
 
 @pytest.mark.gpu
+def test_drop_in_main_fast_mode(binary, golden, tmp_path):
+    """--fast (the non-bit-exact aggregation): runs, writes the 12 images, and differs from the
+    committed disparity maps in a handful of labels only."""
+    PIL = pytest.importorskip("PIL.Image")
+    data = _stage_tsukuba(tmp_path)
+    r = subprocess.run([binary, "--fused", "--fast"], cwd=tmp_path, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    for name in ("disparity_mapl", "disparity_mapr"):
+        got = np.asarray(PIL.open(data / (name + ".png")))
+        diff = int((got != golden[name]).sum())
+        print(name, "pixels that differ from the committed image:", diff)
+        assert diff < 200, (name, diff)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("flags", [["--fused"], ["--host-compare"], ["--fused", "--host-compare"],
                                    ["--ngpu", "1"], ["--fused", "--pairs", "4"], ["--ngpu", "1", "--pairs", "3"],
                                    ["--ngpu", "1", "--overlap", "--pairs", "3"]])
