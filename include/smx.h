@@ -133,6 +133,8 @@ int smx_create(const smx_params* p, int w, int h, int size_d, smx_ctx** ctx);
 int smx_ctx_stereo_pair(smx_ctx* ctx, const uint8_t* gray_l, const uint8_t* gray_r, int dminl, int dminr,
                         const smx_pair_out* out);
 int smx_destroy(smx_ctx* ctx);
+/* Aggregation path of this context (ids as for smx_set_agg_path below). */
+int smx_ctx_set_agg_path(smx_ctx* ctx, int path);
 
 /* ------------------------------------------------------------------------------------
  * Device-pointer API (async on `stream`, no allocation inside)
@@ -191,13 +193,17 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
  * if the GPU is taken away mid-launch; the host-pointer wrappers call it for you. */
 int smx_dev_agg_status(const void* d_workspace);
 
-/* Aggregation implementation: 0 = auto (the fused single-kernel aggregation when radius <= 9, else the
- * multi-kernel path), 1 = force multi-kernel, 2 = force fused (error if radius > 9), 3 = the round-2 fused
- * kernel (kept for A/B timing), 4 = FAST: the fused kernel with wave-parallel row scans -- the additions of
- * the row prefix sums are re-associated, so the results are NOT bit-exact (aggregated volume within 1e-4
- * relative of the reference order, a handful of label flips per map: SURVEY App. C); an upper-bound point
- * that is reported separately, never a default.  Process-wide; for tests and A/B timing.
- * smx_last_agg_path() reports which one the last smx_dev_aggregate_wta[_pair] call on this thread used. */
+/* Aggregation implementation of the calling THREAD's smx_dev_* and host-pointer stage calls (a persistent
+ * context carries its own, smx_ctx_set_agg_path; it starts with the creating thread's):
+ *   0 = auto: the fused single-kernel aggregation when radius <= 9, else the multi-kernel path; the fused call
+ *       picks the comb walker (smx_agg_v5.hip: radius 9, costs built from the images) or the ring walker
+ *       (smx_agg_v4.hip: any radius <= 9, materialised cost volumes)
+ *   1 = force multi-kernel            2 = force fused (error if radius > 9), walker chosen as in auto
+ *   3 = fused, ring walker forced     5 = fused, comb walker forced (error where it does not apply)
+ *   4 = FAST: the ring walker with wave-parallel row scans -- the additions of the row prefix sums are
+ *       re-associated, so the results are NOT bit-exact; reported separately, never a default.
+ * smx_last_agg_path() reports what the last aggregation on this thread ran: 1 multi-kernel, 2 ring walker,
+ * 4 FAST, 5 comb walker. */
 int smx_set_agg_path(int path);
 int smx_last_agg_path(void);
 /* Tile geometry of the fused aggregation for a box radius: output columns per strip, rows per band,

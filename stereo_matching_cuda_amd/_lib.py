@@ -69,6 +69,7 @@ SIGNATURES = {
     "smx_create": (_i, [_PP, _i, _i, _i, C.POINTER(_vp)]),
     "smx_ctx_stereo_pair": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(PairOut)]),
     "smx_destroy": (_i, [_vp]),
+    "smx_ctx_set_agg_path": (_i, [_vp, _i]),
     "smx_dev_rgb_to_grayscale": (_i, [_PP, _vp, _i64, _i, _vp, _vp]),
     "smx_dev_cost_volume": (_i, [_PP, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "smx_dev_integral": (_i, [_vp, _vp, _i, _i, _i, _vp]),

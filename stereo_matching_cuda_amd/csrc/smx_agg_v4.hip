@@ -42,11 +42,13 @@
 
 #include <type_traits>
 
-#include "smx_common.h"
+#include "smx_agg_dev.h"
+#include "smx_agg_v5.h"
 #include "smx_launch.h"
 
 namespace smx {
 namespace v4 {
+using namespace aggdev;
 
 constexpr int OW = 64;                  // output columns per strip = one wave
 constexpr int RMAX = 9;                 // largest supported box radius
@@ -77,11 +79,6 @@ static_assert(RR % 4 == 0 && RR % RPW == 0 && BH % RPW == 0 && RPW % 2 == 0,
 
 enum Src { SRC_IMG = 0, SRC_COST = 1 };
 
-typedef _Float16 fg_t __attribute__((ext_vector_type(2)));   // (pixel value, x-derivative), exact in fp16
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef unsigned u4 __attribute__((ext_vector_type(4)));
-typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 struct View {
     const fg_t* FG1;      // this view's image plane [h][w + 2 PADX], sentinel columns on either side
@@ -102,105 +99,10 @@ struct Args {
     CostConst cc;
 };
 
-// RN(1/d) for d = 0 .. 361 (box areas are (xmax-xmin)*(ymax-ymin) <= 19*19)
-struct RcpTable {
-    float v[HWMAX * HWMAX + 1];
-    constexpr RcpTable() : v() {
-        v[0] = 0.0f;
-        for (int i = 1; i <= HWMAX * HWMAX; ++i) v[i] = 1.0f / (float)i;
-    }
-};
-static __constant__ RcpTable kRcp = RcpTable();
-
-// x / d, correctly rounded, for an integer-valued d in [1, 361] with r = RN(1/d): one residual correction
-// step (Markstein).  Bit-identical to IEEE division for |x| >= 2^-100 (exhaustive over the significand for
-// every area: tools/check_fastdiv.c); callers route smaller |x| (incl. +-0, whose sign the correction would
-// lose) and non-finite x to the true division.
-__device__ __forceinline__ float div_small_int(float x, float d, float r) {
-    float q = x * r;
-    float e = __builtin_fmaf(-q, d, x);
-    return __builtin_fmaf(e, r, q);
-}
-// the same for both components of a cell at once: v_pk_mul_f32 + 2 v_pk_fma_f32 (elementwise, each rounded once:
-// bit-identical to the scalar form)
-__device__ __forceinline__ f2 div_small_int2(f2 x, float d, float r) {
-    const f2 d2 = {d, d}, r2 = {r, r};
-    f2 q = x * r2;
-    f2 e = __builtin_elementwise_fma(-q, d2, x);
-    return __builtin_elementwise_fma(e, r2, q);
-}
-__device__ __forceinline__ bool div_needs_exact(float x) {
-    const float ax = fabsf(x);
-    return !(ax >= 0x1p-100f && ax < __builtin_inff());   // tiny, zero, inf or NaN
-}
-
-// p = (1-alpha)*min(|I1 - I2|, 7) + alpha*min(|g1 - g2|, 2) and I1*p  (costVolume.cu:187,
-// guidedFilter.cu:209).  The halves convert exactly, so the f32 operations equal the reference's; the
-// sentinel 60000 of an out-of-range partner saturates both terms = the border constant (:184).
-__device__ __forceinline__ f2 cost_pair(fg_t q1, fg_t q2, const CostConst& cc) {
-#ifdef SMX_V4_COST_SCALAR
-    const float a1 = (float)q1.x, b1 = (float)q1.y, a2 = (float)q2.x, b2 = (float)q2.y;
-    float t1 = fabsf(a1 - a2);
-    float t2 = fabsf(b1 - b2);
-    float m1 = t1 < cc.th_color ? t1 : cc.th_color;
-    float m2 = t2 < cc.th_grad ? t2 : cc.th_grad;
-    float x = cc.oma * m1;
-    float z = cc.alpha * m2;
-    f2 r;
-    r.x = x + z;
-    r.y = a1 * r.x;
-    return r;
-#else
-    // the same operations, the two differences and the two products as packed instructions, the two selects as
-    // v_min_f32 (no operand is ever a NaN: the inputs are finite halves, so min(|d|, th) == (|d| < th ? |d| : th))
-    const f2 v1 = {(float)q1.x, (float)q1.y}, v2 = {(float)q2.x, (float)q2.y};
-    const f2 d = v1 - v2;
-    const f2 m = {__builtin_fminf(__builtin_fabsf(d.x), cc.th_color), __builtin_fminf(__builtin_fabsf(d.y), cc.th_grad)};
-    const f2 xz = (f2){cc.oma, cc.alpha} * m;
-    f2 r;
-    r.x = xz.x + xz.y;
-    r.y = v1.x * r.x;
-    return r;
-#endif
-}
-
-// ---- hand-off accesses: sc1 (bypass this CU's L1, write through the XCD's L2) ----------------
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr int AUX_SC1 = 16;
-constexpr int AUX_NT = 2;   // q stores and the WTA's q loads are nt: measured best of plain / sc1 / nt
-__device__ __forceinline__ rsrc_t mk_rsrc(const void* p, size_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0,
-                                             (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes),
-                                             0x00020000);
-}
-__device__ __forceinline__ f4 ld16_sc1(rsrc_t r, unsigned byteoff) {
-    return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byteoff, 0, AUX_SC1));
-}
-__device__ __forceinline__ void st16_sc1(rsrc_t r, unsigned byteoff, f4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, (int)byteoff, 0, AUX_SC1);
-}
-__device__ __forceinline__ unsigned ldu(rsrc_t r, unsigned voff, int soff) {
-    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, soff, 0);
-}
-typedef __attribute__((address_space(1))) unsigned gu32;
-__device__ __forceinline__ unsigned flag_load(unsigned* p) {
-    return __hip_atomic_load((gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void flag_store(unsigned* p, unsigned v) {
-    __hip_atomic_store((gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// Workgroup barrier that orders LDS only: __syncthreads() would also wait for every outstanding global
-// load and store, which is exactly the latency the cross-phase prefetches hide.
-__device__ __forceinline__ void wg_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // ---------------------------------------------------------------------------------------------
 // prep: u8 image [h][w] -> (value, x-derivative) half2 plane [h][w + 2 PADX] with PADX sentinel columns on
 // either side.  grid (ceil((w + 2 PADX)/256), h, nimages)      (x_derivativeOnGPU costVolume.cu:358-381)
 // ---------------------------------------------------------------------------------------------
-constexpr int PADX = 4;                 // the aggregation loads four columns per lane: a quad may straddle a border
 struct PrepArgs {
     const uint8_t* I[2];
     fg_t* FG[2];
@@ -440,7 +342,6 @@ constexpr int ITEMLOG_MAX = 1 << 16;
 __device__ unsigned long long g_itemlog[3 * ITEMLOG_MAX];
 #endif
 
-constexpr unsigned FLAG_DONE = 0x7fffffffu;
 // Hand-in hysteresis (experiment, default off): an item that has caught up with its left neighbour meets the slow
 // hand-in -- poll, barrier, exposed cross-XCD load -- in every iteration; with SLACK > 0 it waits once until the
 // neighbour is SLACK records ahead.  Measured on KITTI (1242x375, D=192): SLACK 0 / 2 / 3 / 5 / 8 -> 1.266 / 1.274 /
@@ -459,12 +360,6 @@ constexpr unsigned SLACK = SMX_V4_SLACK;
 #endif
 constexpr int WHATIF = SMX_V4_WHATIF;
 
-// A value the compiler must re-derive where it is used: per-lane constants of the whole item (lane geometry,
-// unit indices) are recomputed from the lane index in a few VALU instructions instead of living in VGPRs
-// across all four phases of every iteration.
-__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
-typedef __attribute__((address_space(3))) const char lds_cc;
-__device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(lds_cc*)p; }
 // one ds_read_b64 the compiler cannot pair into a ds_read2_b64 (which takes four times the LDS cycles of two
 // ds_read_b64 for the same bytes); the caller waits with lds_wait16() before the first use
 #define LDS_RD64(dst, addr, imm) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(imm))
@@ -563,7 +458,6 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
         // for the item + wave-uniform row offset in a scalar register, no 64-bit address arithmetic.  A lane
         // whose column lies outside the image carries the offset OOB, which is beyond every plane: its loads
         // return 0 and its stores are dropped by the range check.
-        constexpr unsigned OOB = 0x80000000u;
         const unsigned fgw4 = ((unsigned)w + 2u * PADX) * 4u, w4 = (unsigned)w * 4u;
         const size_t plane = (size_t)h * w;
         const rsrc_t r_fg1 = mk_rsrc(V.FG1, (size_t)h * fgw4);
@@ -1418,8 +1312,9 @@ size_t v4_workspace_bytes(int w, int h, int nslices) {
     b += align_up(L.plane * 8, 256);                                // (mean_I, 1/(var+eps))
     b += 2 * align_up(L.plane * 4, 256);                            // guidance scratch: integrals of I, I*I
     b += (size_t)nslices * align_up(L.plane * 4, 256);              // q
-    b += align_up((size_t)nslices * L.sv_hand * 4, 256);
-    b += v4_flag_bytes(L, 2 * nslices);                             // control block (shared by both views)
+    const size_t hand5 = v5::sv_hand_floats(h);                    // the comb walker's records (smx_agg_v5.hip)
+    b += align_up((size_t)nslices * (L.sv_hand > hand5 ? L.sv_hand : hand5) * 4, 256);
+    b += v4_flag_bytes(L, 2 * nslices);                             // control block (shared by both views; K of either walker <= L.K)
     return b + 16 * 256;
 }
 
@@ -1479,10 +1374,21 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                  const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
                  const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
                  uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
-                 hipStream_t st, int* launches, bool fast) {
+                 hipStream_t st, int* launches, bool fast, int walker, int* walker_used) {
     const int R = p->radius;
-    const V4Layout L = v4_layout(w, h, R);
+    V4Layout L = v4_layout(w, h, R);
     const bool use_cost = d_cost && d_cost[0];
+    // The comb walker (smx_agg_v5.hip) serves the hot case: radius 9, costs built from the images, exact mode.
+    // walker: 0 = choose, 4 = the ring walker of this file.  Both share this orchestration: image planes, guidance
+    // statistics, chunking, WTA pass; only the strip / band geometry and the records differ.
+    const bool use_v5 = walker != 4 && !use_cost && !fast && v5_supported(p) &&
+                        (size_t)h * ((size_t)w + 2 * v4::PADX) * 24 < 0x80000000ull;   // (its planes share one 32-bit-offset descriptor)
+    if (walker_used) *walker_used = use_v5 ? 5 : 4;
+    if (use_v5) {
+        L.K = v5::strips(w);
+        L.NI = v5::bands(h);
+        L.sv_hand = v5::sv_hand_floats(h);
+    }
     // every plane is addressed through 32-bit buffer offsets, with 0x80000000 as "outside the image"
     if ((size_t)h * ((size_t)w + 2 * v4::PADX) * 8 >= 0x80000000ull)
         return fail(SMX_E_ARG, "aggregate_v4: an image plane of %d x %d exceeds 2 GiB", w, h);
@@ -1508,6 +1414,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     v4::f2* gpair[2];
     for (int i = 0; i < 2; ++i) FG[i] = (v4::fg_t*)carve(L.fg * 4);
     for (int v = 0; v < nviews; ++v) gpair[v] = (v4::f2*)carve(L.plane * 8);
+    const char* const fix_end = base;       // image planes + guidance planes: the comb walker addresses them through one descriptor
     for (int i = 0; i < 2 * nviews; ++i) gs[i] = (float*)carve(L.plane * 4);
     const int total = s_end - s_begin;
     // per slice-view: q plane (unless the caller's volume is written directly) + records + flags
@@ -1599,7 +1506,24 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         a.ticket = (unsigned*)ctrl; a.status = status;
         a.flags = (unsigned*)(ctrl + V4_CTRL_BYTES);
         if (s0 != s_begin) SMX_HIP(hipMemsetAsync(ctrl, 0, v4_flag_bytes(L, a.nsv), st));   // (first chunk: cleared by k_v4_prep)
-        if (fast) rc = use_cost ? launch_walk4<v4::SRC_COST, true>(a, st) : launch_walk4<v4::SRC_IMG, true>(a, st);
+        if (use_v5) {
+            v5::Args b;
+            memset(&b, 0, sizeof(b));
+            b.fix = (const char*)FG[0];
+            b.fix_bytes = (size_t)(fix_end - (const char*)FG[0]);
+            for (int v = 0; v < 2; ++v) {
+                const int vv = v < nviews ? v : 0;
+                b.o_fg[v] = (unsigned)((const char*)FG[v] - b.fix);
+                b.o_guid[v] = (unsigned)((const char*)gpair[vv] - b.fix);
+                b.q[v] = a.v[vv].q;
+                b.d0[v] = a.v[vv].d0;
+            }
+            b.w = w; b.h = h; b.K = L.K; b.NI = L.NI;
+            b.nslices = a.nslices; b.nsv = a.nsv; b.nitems = a.nitems;
+            b.hand = (float*)hand; b.flags = a.flags; b.ticket = a.ticket; b.status = a.status;
+            b.cc = a.cc;
+            rc = v5_launch(b, st);
+        } else if (fast) rc = use_cost ? launch_walk4<v4::SRC_COST, true>(a, st) : launch_walk4<v4::SRC_IMG, true>(a, st);
         else rc = use_cost ? launch_walk4<v4::SRC_COST, false>(a, st) : launch_walk4<v4::SRC_IMG, false>(a, st);
         if (rc) return rc;
         bool al8 = L.plane % 2 == 0;

@@ -1,0 +1,645 @@
+// smx_agg_v5.hip -- fused guided-filter aggregation for gfx950, comb form (radius 9, costs built on the fly):
+// cost build -> integral (p, I*p) -> box -> a_k, b_k -> integral (a, b) -> box -> q in ONE kernel.
+// Reference: guidedFilter.cu:171-238, costVolume.cu:163-190, integral.cu:78-131.
+//
+// What changed against smx_agg_v4.hip: the integral images no longer live in LDS rings.  A work item is a strip
+// of OWS = 285 output columns of one slice-view, walked top -> bottom in bands of BH = 10 rows by one 640-thread
+// workgroup (two per CU).  Its 304 integral-image columns are dealt to COMB lanes: lane i of a 16-lane DPP row
+// with residue r owns column base + 19 i + r, so
+//   * the left box tap (2R+1 = 19 columns to the left) is always lane i-1 of the same DPP row: `row_shr:1` fused
+//     into the subtraction / addition, no LDS access, no bank conflict;
+//   * the column prefix sum S[y][c] = S[y-1][c] + R[y][c] is a register of the lane, and the 19 rows of history the
+//     top taps need are a 20-slot register ring of the lane (static slots: the band loop is unrolled over two
+//     bands = one turn of the ring);
+//   * only the ROW prefix sums go through LDS: a band tile of 10 rows x 304 columns x 2 components per stage,
+//     scanned in place by one wave (lane = (stage, row, component), four columns per LDS instruction, the
+//     reference's left -> right order) and read once by the comb lanes.
+// Waves 0..4 are the combs of stage 1 (p, I p -> a_k, b_k), waves 5..9 those of stage 2 (a, b -> q).
+//
+// Exactness (all checked bit for bit by the CPU model tools/v5_model.cpp against the oracle): virtual rows and
+// columns outside the image hold -0, the exact additive identity, so the clamped window corners of
+// computeBoxFilterOnGPU (guidedFilter.cu:305-318) fall out of the sums themselves (S[y >= h] = S[h-1],
+// S[c >= w] = S[w-1]); a tap that does not exist (no row / column in front of the image) reads +0 from the
+// zero-filled DPP source or the ring's initial state, and v - (+0), v + (+0) are exact because no sum of this
+// path can be -0: every p is >= +0 (costVolume.cu:187) and neither a_k nor b_k can be -0 (x - y == -0 only for
+// x == -0).  That argument needs costs built from the images, so this kernel serves SRC_IMG only; materialised
+// cost volumes and other radii stay on smx_agg_v4.hip.
+//
+// Iteration i of an item (three workgroup barriers, each ordering LDS only):
+//   W(i)  waves 0..4: a_k, b_k of band i-1 (registers since X(i-1)) -> tile 2; hand-off threads: the left
+//         neighbour's record i (stage-2 halo columns -> tile 2, stage-1 row carries -> LDS); everybody: loads of
+//         the stage-1 inputs of band i+1
+//   R(i)  wave 0: row scans of stage 1 (band i, tile 1[i&1]) and stage 2 (a/b band i-1, tile 2)
+//         waves 1..9: evaluate band i+1's costs -> tile 1[(i+1)&1]; drain of the record stores of X(i-1)
+//   X(i)  waves 0..4: S1 += R1, box -> a_k, b_k of rows [10 i - 9, 10 i + 1)   (registers)
+//         waves 5..9: S2 += R2, box -> q rows [10 i - 28, 10 i - 18) -> HBM; record i -> global (sc1)
+// Hand-off, tickets and the bounded flag waits are those of smx_agg_v4.hip (strip-major tickets: the left
+// neighbour of an item always holds an earlier ticket).
+//
+// Must be compiled with -ffp-contract=off.
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "smx_agg_dev.h"
+#include "smx_agg_v5.h"
+
+namespace smx {
+namespace v5 {
+using namespace aggdev;
+
+constexpr int R = 9, HW = 2 * R + 1;
+constexpr int L = 16;                   // lanes of a comb = one DPP row
+constexpr int SW = HW * L;              // 304 integral-image columns per strip (tile columns)
+static_assert(OWS == HW * (L - 1) && SW == OWS + HW, "strip geometry");
+constexpr int RD = 20;                  // ring slots (>= 2R+2; a multiple of BH: static slots)
+static_assert(RD % BH == 0 && RD >= HW + 1, "ring");
+constexpr int NT = 640, NWAVE = NT / 64, NS1 = 5;
+static_assert(NS1 * 64 >= SW && 2 * NS1 == NWAVE, "five comb waves per stage");
+// A tile row is component-planar: first components (p / a) at [0, 304), second ones (I p / b) at [P1, P1 + 304):
+// the row scan moves four columns of one component per LDS instruction, a comb lane reads its cell's pair with
+// one ds_read2st64_b32 (offset1 = P1 / 64).
+constexpr int P1 = 320;
+constexpr int RS = 644;                 // row stride in floats (4 mod 64: the scan lanes of different rows spread over the banks)
+constexpr int TILE_F = BH * RS;
+static_assert(P1 % 64 == 0 && P1 >= SW && RS >= P1 + SW && RS % 4 == 0, "tile row");
+
+// Hand-off record of one band, 16-byte units:
+//   [0, 100)    unit t*10 + jp: stage-2 row prefix of columns 285 + 2 jp, 286 + 2 jp of a/b row t of band i-1 as
+//               (c0[j], c1[j], c0[j+1], c1[j+1])  (column 304 is padding)
+//   [100, 105)  unit 100 + tp: stage-1 running row sums behind tile column 284 of rows 2 tp, 2 tp + 1 of band i
+constexpr int NHU = BH * 10, NCU = BH / 2;
+static_assert(REC_U == NHU + NCU, "record layout");
+
+#ifdef SMX_V5_DUMP
+// Diagnostic build only: tile 1 (current buffer), tile 2 and the comb registers of one item behind the barrier that
+// ends phase SMX_V5_DUMP_PH (0 W, 1 R, 2 X) of iteration SMX_V5_DUMP_IT
+__device__ float g_dump[2 * TILE_F + NT * 48];
+#endif
+
+// ---- DPP row_shr:1 with zero fill, fused into the arithmetic: lane i of a 16-lane row reads lane i-1 of `left`,
+// lane 0 reads +0.  (The compiler keeps a separate v_mov_b32_dpp per tap; the fused forms halve the box.)
+// s_nop 1: a VGPR written by the VALU instruction in front may not be read by DPP for two wait states, and the
+// compiler's hazard recogniser does not look into inline assembly.
+__device__ __forceinline__ float sub_left(float own, float left) {      // own - left[lane-1]
+    float d;
+    asm("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(left), "v"(own));
+    return d;
+}
+__device__ __forceinline__ float add_left(float own, float left) {      // own + left[lane-1]
+    float d;
+    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(left), "v"(own));
+    return d;
+}
+
+// a cell's (first, second) component of a tile row (the compiler forms ds_read2st64_b32 / ds_write2st64_b32:
+// the planes are 5 x 64 dwords apart)
+__device__ __forceinline__ f2 tile_rd(const float* p) { return (f2){p[0], p[P1]}; }
+__device__ __forceinline__ void tile_wr(float* p, f2 v) { p[0] = v.x; p[P1] = v.y; }
+
+template <int DUMMY>
+__global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
+    __shared__ __attribute__((aligned(16))) float tile1[2][TILE_F];
+    __shared__ __attribute__((aligned(16))) float tile2[TILE_F];
+    __shared__ float cin1[BH][2];                                   // stage-1 row carries of the current band
+    __shared__ float rcp_s[RCP_N];                                  // RN(1/area)
+    __shared__ int s_item, s_next;
+    __shared__ unsigned s_seen;                                     // last value read from the left neighbour's flag
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int w = A.w, h = A.h, K = A.K, NI = A.NI, nsv = A.nsv;
+    const CostConst cc = A.cc;
+    const f2 NZ2 = {-0.0f, -0.0f};
+    if (tid < RCP_N) rcp_s[tid] = kRcp.v[tid];
+
+    // ---- comb geometry of this thread: stage, DPP row = residue, position in the comb, tile column ----------
+    const bool st2w = wave >= NS1;
+    // (per-lane values that only one phase of an iteration needs are re-derived from the thread index where they
+    // are used -- a handful of integer instructions per band -- instead of living in VGPRs through the comb rows)
+    auto comb_rho = [&]() { return (64 * (wave - (st2w ? NS1 : 0)) + opaque(lane)) >> 4; };   // DPP row = residue; 19 idles
+    auto comb_jt = [&]() {
+        const int rho = comb_rho(), il = opaque(lane) & 15;
+        return rho < HW ? HW * il + rho : 0;                        // (the 20th DPP row of a stage runs along on column 0)
+    };
+    constexpr int NQROW = SW / 4;                                   // 76 quads per tile row
+    constexpr int NCT = NT - 64;                                    // 576 cost threads (waves 1..9)
+    constexpr int NQB = BH * NQROW - NCT;                           // 184 quads left for round B = 368 pairs
+    static_assert(NQB > 0 && 2 * NQB <= NCT, "two rounds cover the band");
+
+    if (tid == 0) s_item = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        wg_barrier();
+        const int item = s_item;
+        if (item >= A.nitems) break;
+        const int k = item / nsv;
+        const int sv = item - k * nsv;
+        const int view = sv / A.nslices;
+        const int slice = sv - view * A.nslices;
+        const int base1 = OWS * k - 1;          // image column of tile-1 column 0
+        const int base2 = OWS * k - R - 1;      // image column of tile-2 column 0 (= a/b column of the same comb lane)
+        const bool pred = k > 0, succ = k + 1 < K;
+        const int d = A.d0[view] + slice;
+        unsigned* const myflag = A.flags + (size_t)sv * K + k;
+        // Buffer descriptors: ONE over the fixed part of the workspace (both image planes, the guidance plane: the
+        // plane is chosen by a scalar offset), one over the hand-off records, one over this slice's q plane.
+        const unsigned fgw4 = ((unsigned)w + 2u * PADX) * 4u, w4 = (unsigned)w * 4u;
+        const size_t plane = (size_t)h * w;
+        const rsrc_t r_fix = mk_rsrc(A.fix, A.fix_bytes);
+        const int o_fg1 = (int)A.o_fg[view], o_fg2 = (int)A.o_fg[view ^ 1], o_g = (int)A.o_guid[view];
+        const unsigned recb = (unsigned)NI * REC_U * 16u;        // bytes per (parity, slice-view)
+        const rsrc_t r_hand = mk_rsrc(A.hand, (size_t)2 * nsv * recb);
+        const int o_in = (int)((((unsigned)(k - 1) & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
+        const int o_out = (int)((((unsigned)k & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
+        const rsrc_t r_q = mk_rsrc(A.q[view] + (size_t)slice * plane, plane * 4);
+
+        // the strip has columns outside the image (virtual: -0)
+        const bool xedge = base1 < 0 || base1 + SW > w;
+        auto item_body = [&](auto ST2c) {
+        constexpr bool ST2 = decltype(ST2c)::value;
+        // ---- per-lane constants of the item that every comb row needs ------------------------------------------
+        const int jt = comb_jt();                                   // tile column
+        int xw;                                                     // window width of this lane's output column
+        float rcp_i;                                                // 1 / (19 xw): interior rows
+        unsigned vo;                                                // byte offset of the output column: guidance pair (stage 1), q (stage 2; the guidance image value sits PADX further)
+        bool col_ok;
+        {
+            const int il = lane & 15;
+            const int xo = (ST2 ? base2 - R : base2) + jt;          // a/b column (stage 1) / q column (stage 2)
+            col_ok = comb_rho() < HW && xo >= 0 && xo < w && (!ST2 || il >= 1);
+            xw = col_ok ? min(w - 1, xo + R) - max(-1, xo - R - 1) : 1;
+            rcp_i = rcp_s[HW * xw];
+            vo = col_ok ? (unsigned)xo * (ST2 ? 4u : 8u) : OOB;
+        }
+        const f2 area2_i = {(float)(HW * xw), (float)(HW * xw)}, rcp2_i = {rcp_i, rcp_i};
+
+        // ---- register state ------------------------------------------------------------------------------------
+        f2 ring[RD];                         // ring[y mod RD] = S[y] of this lane's column; the slot of row y-1 is the running sum
+#pragma unroll
+        for (int s = 0; s < RD; ++s) ring[s] = (f2){0.0f, 0.0f};
+        ring[ST2 ? 10 : RD - 1] = NZ2;   // the slot in front of the first row (stage 1: row 0; stage 2: row -9)
+        // (arrays of the other role shrink to one element: the two roles are separate instantiations, so that no
+        // register carries state of the other role around the band loop)
+        f2 abreg[ST2 ? 1 : BH];              // stage 1: a_k, b_k of this lane's rows, written to tile 2 in the next W phase
+#pragma unroll
+        for (int t = 0; t < (ST2 ? 1 : BH); ++t) abreg[t] = NZ2;
+        constexpr int GPF = 4;               // guidance rows in flight per lane
+        f2 gq[ST2 ? 1 : GPF];                // stage 1: (mean_I, 1/(var+eps))
+        unsigned gI[ST2 ? GPF : 1];          // stage 2: raw (value, gradient) halves of the guidance image
+        u4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};   // round-A raw quads of the two images
+        u2 pa = {0, 0}, pb = {0, 0};               // round-B raw pairs
+        f4 hreg = {0, 0, 0, 0};              // (stage-2 role) this thread's unit of the left neighbour's next record
+        bool have_pref = false;
+        unsigned seen = 0;
+
+        // stage-1 input units of this thread (waves 1..9): round A one quad, round B one pair; tile offsets and the
+        // byte offsets in the two image planes without the band term
+        struct CostGeo { int a_row, a_col, b_row, b_col; bool b_on; };
+        auto cost_geo = [&]() {
+            CostGeo g;
+            const int ct = max(opaque(tid) - 64, 0);
+            g.a_row = ct / NQROW;
+            g.a_col = (ct - g.a_row * NQROW) * 4;
+            const int u = NCT + (ct >> 1), ur = u / NQROW;
+            g.b_row = min(ur, BH - 1);
+            g.b_col = (u - ur * NQROW) * 4 + 2 * (ct & 1);
+            g.b_on = ct < 2 * NQB;
+            return g;
+        };
+        // loads of the stage-1 inputs of band ib (rows clamped into the image: every load is issued)
+        auto issue_cost = [&](int ib) {
+            if (wave == 0) return;
+            const CostGeo g = cost_geo();
+            auto off = [&](int row, int col, int dd) {
+                const int y = min(BH * ib + row, h - 1);
+                return (unsigned)(min(max(base1 + col + dd, -PADX), w) + PADX) * 4u + (unsigned)y * fgw4;
+            };
+            ra = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(g.a_row, g.a_col, 0), o_fg1, 0);
+            rb = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(g.a_row, g.a_col, d), o_fg2, 0);
+            pa = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)off(g.b_row, g.b_col, 0), o_fg1, 0);
+            pb = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)off(g.b_row, g.b_col, d), o_fg2, 0);
+        };
+        // raw -> (p, I p) -> tile 1 buffer `dst` (band ib); cells outside the image are -0
+        auto eval_cost = [&](int ib, float* dst) {
+            if (wave == 0) return;
+            const CostGeo g = cost_geo();
+            const bool edge = xedge || BH * ib + BH > h;
+            {
+                const unsigned r1[4] = {ra.x, ra.y, ra.z, ra.w}, r2[4] = {rb.x, rb.y, rb.z, rb.w};
+                f4 px, py;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f2 v = cost_pair(__builtin_bit_cast(fg_t, r1[j]), __builtin_bit_cast(fg_t, r2[j]), cc);
+                    if (edge) {
+                        const int c = base1 + g.a_col + j;
+                        if (!(c >= 0 && c < w && BH * ib + g.a_row < h)) v = NZ2;
+                    }
+                    px[j] = v.x; py[j] = v.y;
+                }
+                float* p = dst + g.a_row * RS + g.a_col;
+                *(f4*)p = px;
+                *(f4*)(p + P1) = py;
+            }
+            if (g.b_on) {
+                const unsigned r1[2] = {pa.x, pa.y}, r2[2] = {pb.x, pb.y};
+                f2 px, py;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f2 v = cost_pair(__builtin_bit_cast(fg_t, r1[j]), __builtin_bit_cast(fg_t, r2[j]), cc);
+                    if (edge) {
+                        const int c = base1 + g.b_col + j;
+                        if (!(c >= 0 && c < w && BH * ib + g.b_row < h)) v = NZ2;
+                    }
+                    px[j] = v.x; py[j] = v.y;
+                }
+                float* p = dst + g.b_row * RS + g.b_col;
+                *(f2*)p = px;
+                *(f2*)(p + P1) = py;
+            }
+        };
+        // guidance of output row yrow -> slot (rows clamped into the image: every load is issued)
+        // (the rows an interior band asks for all exist: no clamp)
+        auto issue_guid = [&](int slot, int yrow, bool clamp) {
+            const int y = clamp ? min(max(yrow, 0), h - 1) : yrow;
+            if constexpr (!ST2) {
+                const u2 g = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)vo, o_g + y * (int)(2u * w4), 0);
+                gq[slot] = __builtin_bit_cast(f2, g);
+            } else {
+                gI[slot] = ldu(r_fix, vo + 4u * PADX, o_fg1 + y * (int)fgw4);
+            }
+        };
+
+        // hand-off unit of this thread (waves 5..): index hq < REC_U; halo units: row, first of its two columns
+        auto hu_idx = [&]() { return opaque(tid) - 64 * NS1; };
+        auto fetch_rec = [&](int rec) {
+            const int hq = hu_idx();
+            hreg = ld16_sc1(r_hand, (unsigned)(o_in + rec * REC_U * 16) + (hq >= 0 && hq < REC_U ? (unsigned)hq * 16u : 0u));
+        };
+        // bounded wait for the left neighbour's flag >= need (thread 0 only); result -> s_seen
+        auto spin_pred = [&](unsigned need) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                const unsigned f = flag_load(myflag - 1);
+                if (f >= need) { s_seen = f; break; }
+                __builtin_amdgcn_s_sleep(4);
+                // give up after 2 s (100 MHz counter) or as soon as any workgroup has given up; the call then
+                // reports SMX_E_HIP through smx_dev_agg_status
+                if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull || flag_load(A.status) != 0u) {
+                    flag_store(A.status, 1u + (unsigned)item);
+                    s_seen = FLAG_DONE;
+                    break;
+                }
+            }
+        };
+
+        // ---- row scans of iteration i (wave 0): lanes 0..19 stage 1, lanes 32..51 stage 2; lane = (row, component)
+        auto rowscans = [&](int i, float* t1) {
+            const int sc_l = lane & 31, sc_st = lane >> 5, sc_row = sc_l % BH, sc_comp = sc_l / BH;
+            const int y = sc_st == 0 ? BH * i + sc_row : BH * (i - 1) - R + sc_row;
+            const bool act = sc_l < 2 * BH && y >= 0 && y < h && (sc_st == 0 || i >= 1);
+            if (!act) return;
+            float* const row = (sc_st == 0 ? t1 : tile2) + sc_row * RS + sc_comp * P1;
+            // stage 1 starts from the left neighbour's running row sum (or -0); stage 2 of a strip with a left
+            // neighbour leaves the 19 halo columns alone and starts behind them from the halo's last column
+            const bool keep = sc_st == 1 && pred;
+            float acc = (sc_st == 0 && pred) ? cin1[sc_row][sc_comp] : -0.0f;
+            f4* const r4 = (f4*)row;
+            constexpr int NG = SW / 4, PF = 6;
+            f4 v[PF];
+#pragma unroll
+            for (int g = 0; g < PF; ++g) v[g] = r4[g];
+            // groups 0 .. 4 (columns 0 .. 19): the variant that can leave the halo columns 0 .. 18 untouched
+#pragma unroll
+            for (int g = 0; g < 5; ++g) {
+                const f4 in = v[g % PF];
+                v[g % PF] = r4[g + PF];
+                f4 x;
+                acc = in.x + acc; x.x = acc;
+                acc = in.y + acc; x.y = acc;
+                acc = in.z + acc; x.z = acc;
+                if (g == 4 && keep) acc = in.z;            // column 18 = the halo's last: the carry
+                acc = in.w + acc; x.w = acc;
+                if (keep) { x.x = in.x; x.y = in.y; x.z = in.z; if (g < 4) x.w = in.w; }
+                r4[g] = x;
+            }
+            // groups 5 .. 75: PF groups of reads ahead of the dependent adds (past the end they re-read the last group)
+            for (int g0 = 5; g0 < NG; g0 += PF) {
+#pragma unroll
+                for (int u = 0; u < PF; ++u) {
+                    const int g = g0 + u;
+                    if (g < NG) {
+                        const f4 in = v[(5 + u) % PF];
+                        v[(5 + u) % PF] = r4[min(g + PF, NG - 1)];
+                        f4 x;
+                        acc = in.x + acc; x.x = acc;
+                        acc = in.y + acc; x.y = acc;
+                        acc = in.z + acc; x.z = acc;
+                        acc = in.w + acc; x.w = acc;
+                        r4[g] = x;
+                    }
+                }
+            }
+        };
+
+        // ---- comb rows ---------------------------------------------------------------------------------------------
+        // box sum S11 - S10 - S01 + S00 (computeBoxFilterOnGPU guidedFilter.cu:305-318, that order) of ring slot SL
+        // (bottom taps) and SL01 (top taps, 19 rows up): left taps = lane i-1 of the DPP row
+#define V5_BOX(u, SL, SL01)                                    \
+    do {                                                       \
+        u.x = sub_left(ring[SL].x, ring[SL].x);                \
+        u.y = sub_left(ring[SL].y, ring[SL].y);                \
+        u = u - ring[SL01];                                    \
+        u.x = add_left(u.x, ring[SL01].x);                     \
+        u.y = add_left(u.y, ring[SL01].y);                     \
+    } while (0)
+        // window area of output row y and 1/area for this lane, as pairs for the packed division (border bands:
+        // clipped window height, table look-up)
+        auto area_of = [&](int y, auto BORDERc, f2& area2, f2& rcp2) {
+            if constexpr (decltype(BORDERc)::value) {
+                const int yc = min(max(y, 0), h - 1);
+                const int yh = min(h - 1, yc + R) - max(-1, yc - R - 1);
+                const int ai = xw * yh;
+                const float a = (float)ai, r = rcp_s[ai];
+                area2 = (f2){a, a};
+                rcp2 = (f2){r, r};
+            } else {
+                area2 = area2_i;
+                rcp2 = rcp2_i;
+            }
+        };
+        auto div2 = [&](f2 x, f2 d2, f2 r2) {           // div_small_int2 with ready-made pairs
+            f2 q = x * r2;
+            f2 e = __builtin_elementwise_fma(-q, d2, x);
+            return __builtin_elementwise_fma(e, r2, q);
+        };
+
+        // One comb row of stage 1: T = row of the band, N = T + 10 * (band parity) = ring slot of its image row.
+        // rv = this row's (R1 p, R1 Ip) pair, read from the tile one row ahead; rows are separate scheduling regions
+        // (the compiler otherwise runs the ten column sums first and keeps every tap of the band alive).
+        auto row1 = [&](auto Nc, auto BORDERc, int i, const float* t1, f2& rv) {
+            constexpr int N = decltype(Nc)::value, T = N % BH, SL = N, SL01 = (N + 1) % RD, SLP = (N + RD - 1) % RD;
+            constexpr bool BORDER = decltype(BORDERc)::value;
+            const f2 rvn = tile_rd(t1 + (T + 1 < BH ? T + 1 : T) * RS + jt);
+            ring[SL] = rv + ring[SLP];                     // colSum integral.cu:124-128
+            f2 u;
+            V5_BOX(u, SL, SL01);
+            f2 area2, rcp2;
+            area_of(BH * i - R + T, BORDERc, area2, rcp2);
+            const f2 m = div2(u, area2, rcp2);             // (mean_p, mean_Ip); no window sum of p, I p can be tiny (smx_agg_v5.h)
+            const f2 g = gq[N % GPF];
+            // compute_ak_and_bk guidedFilter.cu:345-354
+            const float mm = g.x * m.x;
+            const float ak = 1.0f * (m.y - mm) * g.y;
+            const float mb2 = 1.0f * g.x * ak;
+            const float bk = 1.0f * m.x - mb2;
+            abreg[T] = (f2){ak, bk};
+            // the guidance of the row GPF rows further down (next band: its first rows)
+            issue_guid(N % GPF, BH * i - R + T + GPF, BORDER);
+            rv = rvn;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // one comb row of stage 2 (a/b band i-1): ring slot of a/b row 10 (i-1) - 9 + T
+        auto row2 = [&](auto Nc, auto BORDERc, int i, f2& rv) {
+            constexpr int N = decltype(Nc)::value, T = N % BH, PAR = N / BH;
+            constexpr int SL = (BH * (PAR ^ 1) + T + 11) % RD, SL01 = (SL + 1) % RD, SLP = (SL + RD - 1) % RD;
+            constexpr bool BORDER = decltype(BORDERc)::value;
+            const f2 rvn = tile_rd(tile2 + (T + 1 < BH ? T + 1 : T) * RS + jt);
+            ring[SL] = rv + ring[SLP];
+            f2 u;
+            V5_BOX(u, SL, SL01);
+            const int yq = BH * (i - 1) - 2 * R + T;
+            f2 area2, rcp2;
+            area_of(yq, BORDERc, area2, rcp2);
+            f2 m = div2(u, area2, rcp2);
+            // tiny (or zero) window sums of a, b take the true division (wave-uniform, rare); lanes without an
+            // output do not vote
+            const float amin = fminf(fabsf(u.x), fabsf(u.y));
+            if (__any(col_ok && !(amin >= 0x1p-100f))) {
+                asm volatile("; exact-division slow path");
+                m.x = 1.0f * u.x / area2.x;
+                m.y = 1.0f * u.y / area2.x;
+            }
+            const float Iv = (float)__builtin_bit_cast(fg_t, gI[N % GPF]).x;
+            const float tq = m.x * Iv;                     // compute_q guidedFilter.cu:363-369
+            const float qv = tq + m.y;
+            if (!BORDER || (yq >= 0 && yq < h))
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qv), r_q, (int)vo, yq * (int)w4, AUX_NT);
+            issue_guid(N % GPF, yq + GPF, BORDER);
+            rv = rvn;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        // ===================================== the band loop ==============================================
+        // prologue: stage-1 inputs of band 0 -> tile 1[0]; guidance of the first rows; the left neighbour's record 0
+        issue_cost(0);
+        // (stage 2 starts at i = 1 with comb rows N = 10 .. 13: slots 2, 3, 0, 1)
+        if constexpr (ST2) {
+#pragma unroll
+            for (int s = 0; s < GPF; ++s) issue_guid((BH + s) % GPF, -2 * R + s, true);
+        } else {
+#pragma unroll
+            for (int s = 0; s < GPF; ++s) issue_guid(s, -R + s, true);
+        }
+        if (pred) {
+            if (tid == 0) spin_pred(1u);
+            wg_barrier();
+            seen = s_seen;
+        }
+        if constexpr (ST2) fetch_rec(0);
+        have_pref = pred;
+        eval_cost(0, tile1[0]);
+
+        auto band = [&](auto PARc, int i) {
+            constexpr int PAR = decltype(PARc)::value;
+            float* const t1 = tile1[PAR];
+            float* const t1n = tile1[PAR ^ 1];
+            // ------------------------------------ W(i) --------------------------------------------------
+            if (pred && !have_pref) {
+                // the neighbour had not published record i when this item looked: wait for it now
+                if (tid == 0) spin_pred((unsigned)i + 1u);
+                wg_barrier();
+                seen = s_seen;
+                if constexpr (ST2) fetch_rec(i);
+            }
+            if constexpr (!ST2) {
+                // a/b rows [10 (i-1) - 9, 10 (i-1) + 1) of X(i-1) -> tile 2 column jt; rows / columns outside the image:
+                // -0; the 19 halo columns of a strip with a left neighbour come from its record instead
+                const int il = opaque(lane) & 15;
+                const bool wr = comb_rho() < HW && !(pred && il == 0);
+                if (i >= 1 && wr) {
+                    const int ya0 = BH * (i - 1) - R;
+                    const bool redge = ya0 < 0 || ya0 + BH > h;
+                    const int xo = base2 + jt;
+                    const bool cok = xo >= 0 && xo < w;
+#pragma unroll
+                    for (int t = 0; t < BH; ++t) {
+                        f2 v = abreg[t];
+                        if (redge || xedge) {
+                            const int ya = ya0 + t;
+                            if (!(ya >= 0 && ya < h && cok)) v = NZ2;
+                        }
+                        tile_wr(tile2 + t * RS + jt, v);
+                    }
+                }
+            } else { if (pred) {
+                const int hq = hu_idx();
+                if (hq >= 0 && hq < NHU) {
+                    if (i >= 1) {
+                        const int t = hq / 10, j = (hq - 10 * t) * 2;
+                        float* dst = tile2 + t * RS + j;
+                        dst[0] = hreg.x;
+                        dst[P1] = hreg.y;
+                        if (j + 1 < HW) { dst[1] = hreg.z; dst[P1 + 1] = hreg.w; }
+                    }
+                } else if (hq >= NHU && hq < REC_U) {
+                    const int tp = hq - NHU;
+                    cin1[2 * tp][0] = hreg.x; cin1[2 * tp][1] = hreg.y;
+                    cin1[2 * tp + 1][0] = hreg.z; cin1[2 * tp + 1][1] = hreg.w;
+                }
+            } }
+            have_pref = false;
+            issue_cost(i + 1);                 // lands under the row scans
+            wg_barrier();
+#ifdef SMX_V5_DUMP
+            if (item == SMX_V5_DUMP && i == SMX_V5_DUMP_IT && SMX_V5_DUMP_PH == 0) {
+                for (int e = tid; e < TILE_F; e += NT) { g_dump[e] = t1[e]; g_dump[TILE_F + e] = tile2[e]; }
+                wg_barrier();
+            }
+#endif
+            // ------------------------------------ R(i) --------------------------------------------------
+            if (wave == 0) {
+                __builtin_amdgcn_s_setprio(3);
+                rowscans(i, t1);
+                __builtin_amdgcn_s_setprio(0);
+            } else {
+                if (wave == NWAVE - 1 && lane == 63) {
+                    // an otherwise idle lane looks at the left neighbour's flag for the prefetch of record i+1
+                    if (pred && seen != FLAG_DONE && seen < (unsigned)i + 2u) s_seen = flag_load(myflag - 1);
+                    // ticket of the next item, one iteration before the end
+                    if (i == NI - 1)
+                        s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                eval_cost(i + 1, t1n);
+                // every storing wave drains its global accesses before the barrier behind which one lane publishes
+                // the record stored in X(i-1)
+                if constexpr (ST2) drain_vmem();
+            }
+            wg_barrier();
+#ifdef SMX_V5_DUMP
+            if (item == SMX_V5_DUMP && i == SMX_V5_DUMP_IT && SMX_V5_DUMP_PH == 1) {
+                for (int e = tid; e < TILE_F; e += NT) { g_dump[e] = t1[e]; g_dump[TILE_F + e] = tile2[e]; }
+                wg_barrier();
+            }
+#endif
+            // ------------------------------------ X(i) --------------------------------------------------
+            if (succ && tid == NT - 1 && i >= 1) flag_store(myflag, (unsigned)i);
+            seen = s_seen;
+            if constexpr (!ST2) {
+                // an interior band: every window of its a/b rows is unclipped in y, and so are the rows GPF further down
+                const bool border = BH * i - R < R + 1 || BH * i - R + BH - 1 + GPF > h - 1 - R;
+                // (idle comb lanes -- the 20th DPP row -- run along on tile column 0: no branch around the loads)
+                f2 rv = tile_rd(t1 + jt);
+                __builtin_amdgcn_sched_barrier(0);
+#define V5_R1(TT, B) row1(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, i, t1, rv);
+                if (border) { V5_R1(0, true) V5_R1(1, true) V5_R1(2, true) V5_R1(3, true) V5_R1(4, true) V5_R1(5, true) V5_R1(6, true) V5_R1(7, true) V5_R1(8, true) V5_R1(9, true) }
+                else { V5_R1(0, false) V5_R1(1, false) V5_R1(2, false) V5_R1(3, false) V5_R1(4, false) V5_R1(5, false) V5_R1(6, false) V5_R1(7, false) V5_R1(8, false) V5_R1(9, false) }
+#undef V5_R1
+            } else {
+                // the left neighbour's record i+1 is needed first thing in the next iteration: its load goes out now
+                // (unconditionally: a load under a condition is waited for where the branches merge); what it
+                // returns counts only if the record had been published
+                fetch_rec(min(i + 1, NI - 1));
+                if (i >= 1) {
+                    const int yq0 = BH * (i - 1) - 2 * R;
+                    const bool border = yq0 < R + 1 || yq0 + BH - 1 + GPF > h - 1 - R;
+                    f2 rv = tile_rd(tile2 + jt);
+                    __builtin_amdgcn_sched_barrier(0);
+#define V5_R2(TT, B) row2(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, i, rv);
+                    if (border) { V5_R2(0, true) V5_R2(1, true) V5_R2(2, true) V5_R2(3, true) V5_R2(4, true) V5_R2(5, true) V5_R2(6, true) V5_R2(7, true) V5_R2(8, true) V5_R2(9, true) }
+                    else { V5_R2(0, false) V5_R2(1, false) V5_R2(2, false) V5_R2(3, false) V5_R2(4, false) V5_R2(5, false) V5_R2(6, false) V5_R2(7, false) V5_R2(8, false) V5_R2(9, false) }
+#undef V5_R2
+                }
+                const int hq = hu_idx();
+                if (succ && hq >= 0 && hq < REC_U) {
+                    // record i: stage-2 row prefix of the strip's last 19 columns (a/b band i-1), stage-1 row carries
+                    f4 hov;
+                    if (hq < NHU) {
+                        const int t = hq / 10, j = (hq - 10 * t) * 2;
+                        const float* p = tile2 + t * RS + OWS + j;
+                        hov = (f4){p[0], p[P1], p[1], p[P1 + 1]};
+                    } else {
+                        const float* p = t1 + 2 * (hq - NHU) * RS + OWS - 1;
+                        hov = (f4){p[0], p[P1], p[RS], p[RS + P1]};
+                    }
+                    st16_sc1(r_hand, (unsigned)(o_out + i * REC_U * 16) + (unsigned)hq * 16u, hov);
+                }
+            }
+            have_pref = pred && (seen == FLAG_DONE || seen >= (unsigned)i + 2u);
+            wg_barrier();
+#ifdef SMX_V5_DUMP
+            if (item == SMX_V5_DUMP && i == SMX_V5_DUMP_IT && SMX_V5_DUMP_PH == 2) {
+                for (int e = tid; e < TILE_F; e += NT) { g_dump[e] = t1[e]; g_dump[TILE_F + e] = tile2[e]; }
+#pragma unroll
+                for (int s = 0; s < RD; ++s) { g_dump[2 * TILE_F + tid * 48 + 2 * s] = ring[s].x; g_dump[2 * TILE_F + tid * 48 + 2 * s + 1] = ring[s].y; }
+                wg_barrier();
+            }
+#endif
+        };
+        for (int i = 0; i < NI; i += 2) {
+            band(std::integral_constant<int, 0>{}, i);
+            if (i + 1 < NI) band(std::integral_constant<int, 1>{}, i + 1);
+        }
+        };
+        if (st2w) item_body(std::true_type{}); else item_body(std::false_type{});
+        // the last record and the last q rows: drained, then published
+        drain_vmem();
+        wg_barrier();
+        if (tid == 0) {
+            if (succ) flag_store(myflag, FLAG_DONE);
+            s_item = s_next;
+        }
+    }
+}
+#undef V5_BOX
+
+}  // namespace v5
+
+bool v5_supported(const smx_params* p) {
+    if (p->radius != v5::R) return false;
+    if (!(p->eps >= 1.0) || !(p->eps < 1e30)) return false;
+    const CostConst c = make_cost_const(p);
+    if (!(c.alpha >= 0.0f && c.alpha <= 1.0f && c.th_color >= 0.0f && c.th_color < 1e6f && c.th_grad >= 0.0f && c.th_grad < 1e6f))
+        return false;
+    // smallest nonzero truncated terms: |dI| >= 1 (integers), |dg| >= 0.5 (halves), or the thresholds themselves
+    const float m1 = c.th_color < 1.0f ? c.th_color : 1.0f, m2 = c.th_grad < 0.5f ? c.th_grad : 0.5f;
+    const float t1 = c.oma * m1, t2 = c.alpha * m2;
+    auto ok = [](float t) { return t == 0.0f || t >= 0x1p-60f; };
+    return ok(t1) && ok(t2);
+}
+
+int v5_launch(const v5::Args& a, hipStream_t st) {
+    int dev = 0, ncu = 256;
+    SMX_HIP(hipGetDevice(&dev));
+    SMX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    int per_cu = v5::WG_PER_CU;                          // persistent: WG_PER_CU workgroups per CU
+    if (const char* e = getenv("SMX_V5_WG_PER_CU")) {    // experiments: fewer workgroups per CU
+        const int v = atoi(e);
+        if (v >= 1 && v <= v5::WG_PER_CU) per_cu = v;
+    }
+    const int slots = per_cu * ncu;
+    const int grid = a.nitems < slots ? a.nitems : slots;
+    hipLaunchKernelGGL((v5::k_v5_walk<0>), dim3((unsigned)grid), dim3(v5::NT), 0, st, a);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+#ifdef SMX_V5_DUMP
+extern "C" __attribute__((visibility("default"))) int smx_debug_read_dump5(float* out, int n) {
+    const int m = 2 * v5::TILE_F + v5::NT * 48;
+    SMX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(v5::g_dump), sizeof(float) * (n < m ? n : m)));
+    return m;
+}
+#endif
+
+}  // namespace smx

@@ -18,42 +18,41 @@ static thread_local int g_launches = 0;
 #ifndef SMX_DEFAULT_AGG_PATH
 #define SMX_DEFAULT_AGG_PATH 0
 #endif
-static int g_agg_path = SMX_DEFAULT_AGG_PATH;   // 0 auto, 1 force multi-kernel, 2 force fused, 3 force the round-2 fused kernel, 4 fused FAST (not bit-exact)
+// Aggregation path of the calling thread's smx_dev_* / host-pointer calls (smx_set_agg_path); a persistent
+// context carries its own (smx_ctx_set_agg_path).  0 auto, 1 multi-kernel, 2 fused (walker chosen by the call),
+// 3 fused with the ring walker (smx_agg_v4.hip), 4 fused FAST (not bit-exact), 5 fused with the comb walker
+// (smx_agg_v5.hip; an error where it does not apply)
+static thread_local int g_agg_path = SMX_DEFAULT_AGG_PATH;
 static thread_local int g_last_path = 0;
 
-// smx_agg_v3.hip
-bool v3_supported(const smx_params* p);
-size_t v3_workspace_bytes(int w, int h, int nslices);
-int aggregate_v3(const smx_params* p, int nviews, const uint8_t* const* d_guide,
-                 const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
-                 const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
-                 uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
-                 hipStream_t st, int* launches);
-
-int v3_read_status(const void* d_ws, unsigned* out);
-void v3_geometry(int* ow, int* bh);
-
-// smx_agg_v4.hip
+// smx_agg_v4.hip (host orchestration of both fused walkers)
 bool v4_supported(const smx_params* p);
 size_t v4_workspace_bytes(int w, int h, int nslices);
 int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                  const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
                  const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
                  uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
-                 hipStream_t st, int* launches, bool fast);
+                 hipStream_t st, int* launches, bool fast, int walker, int* walker_used);
+int v4_read_status(const void* d_ws, unsigned* out);
 void v4_geometry(int* ow, int* bh);
+// smx_agg_v5.hip
+bool v5_supported(const smx_params* p);
 
-// the fused aggregation: smx_agg_v4.hip, or its predecessor smx_agg_v3.hip when path 3 is forced (A/B timing)
-static int aggregate_fused(const smx_params* p, int nviews, const uint8_t* const* d_guide,
+// the fused aggregation; reports the path that ran: 2 = ring walker, 4 = FAST, 5 = comb walker
+static int aggregate_fused(int path, const smx_params* p, int nviews, const uint8_t* const* d_guide,
                            const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
                            const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
                            uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
                            hipStream_t st, int* launches) {
-    if (g_agg_path == 3)
-        return aggregate_v3(p, nviews, d_guide, d_other, d_cost, w, h, dmin, s_begin, s_end, d_keys, d_mean_u8,
-                            d_agg, d_ws, ws_bytes, st, launches);
-    return aggregate_v4(p, nviews, d_guide, d_other, d_cost, w, h, dmin, s_begin, s_end, d_keys, d_mean_u8,
-                        d_agg, d_ws, ws_bytes, st, launches, g_agg_path == 4);
+    int used = 0;
+    const bool cost_in = d_cost && d_cost[0];
+    if (path == 5 && (cost_in || !v5_supported(p)))
+        return fail(SMX_E_ARG, "aggregation path 5 (comb walker) needs radius 9, costs built from the images and default-like cost parameters");
+    int rc = aggregate_v4(p, nviews, d_guide, d_other, d_cost, w, h, dmin, s_begin, s_end, d_keys, d_mean_u8,
+                          d_agg, d_ws, ws_bytes, st, launches, path == 4, path == 3 || path == 4 ? 4 : 0, &used);
+    if (rc) return rc;
+    g_last_path = path == 4 ? 4 : (used == 5 ? 5 : 2);
+    return SMX_OK;
 }
 
 int fail(int code, const char* fmt, ...) {
@@ -156,14 +155,12 @@ size_t smx_agg_workspace_bytes(int w, int h, int nslices) {
     if (w < 1 || h < 1 || nslices < 1) return 0;
     // v1 path: guidance im, mean_im, cinv, S_im, S_sq ; per slice in flight: cost, T0, T1, A, B
     const size_t v1 = plane_bytes(w, h) * (5 + 5 * (size_t)nslices) + 2 * WS_ALIGN;
-    const size_t v3b = v3_workspace_bytes(w, h, nslices);
-    const size_t v4b = v4_workspace_bytes(w, h, nslices);
-    const size_t f = v3b > v4b ? v3b : v4b;
+    const size_t f = v4_workspace_bytes(w, h, nslices);
     return v1 > f ? v1 : f;
 }
 
 int smx_set_agg_path(int path) {
-    if (path < 0 || path > 4) return fail(SMX_E_ARG, "smx_set_agg_path: path must be 0 .. 4");
+    if (path < 0 || path > 5) return fail(SMX_E_ARG, "smx_set_agg_path: path must be 0 .. 5");
     g_agg_path = path;
     return SMX_OK;
 }
@@ -172,8 +169,11 @@ int smx_last_agg_path(void) { return g_last_path; }
 
 int smx_agg_geometry(int radius, int* strip_cols, int* band_rows, int* tile_cols) {
     int ow = 0, bh = 0;
-    if (g_agg_path == 3) v3_geometry(&ow, &bh);
-    else v4_geometry(&ow, &bh);
+    v4_geometry(&ow, &bh);
+    smx_params p;
+    smx_default_params(&p);
+    p.radius = radius;
+    if (g_agg_path != 3 && g_agg_path != 4 && v5_supported(&p)) { ow = 285; bh = 10; }   // the comb walker (smx_agg_v5.h)
     if (strip_cols) *strip_cols = ow;
     if (band_rows) *band_rows = bh;
     if (tile_cols) *tile_cols = ow + 2 * radius + 1;
@@ -183,7 +183,7 @@ int smx_agg_geometry(int radius, int* strip_cols, int* band_rows, int* tile_cols
 int smx_dev_agg_status(const void* d_workspace) {
     SMX_ARG(d_workspace);
     unsigned st = 0;
-    int rc = v3_read_status(d_workspace, &st);
+    int rc = v4_read_status(d_workspace, &st);
     if (rc) return rc;
     if (st != 0)
         return fail(SMX_E_HIP, "fused aggregation: hand-off wait of work item %u timed out (results invalid)",
@@ -261,21 +261,20 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
     SMX_ARG(w >= 2 && h >= 1 && s_begin >= 0 && s_end >= s_begin && p->radius >= 0);
     { int rcd = check_same_device(d_workspace, "smx_dev_aggregate_wta"); if (rcd) return rcd; }
     hipStream_t st = (hipStream_t)stream;
-    // fused path (smx_agg_v3.hip): radius <= 9; cost built on the fly or read from d_cost
-    const bool can_v3 = v3_supported(p) && v4_supported(p);
-    if (g_agg_path == 2 && !can_v3)
+    // fused path: radius <= 9; cost built on the fly or read from d_cost
+    const bool can_fuse = v4_supported(p);
+    if (g_agg_path >= 2 && !can_fuse)
         return fail(SMX_E_ARG, "smx_dev_aggregate_wta: fused path forced but radius > 9");
-    if (can_v3 && g_agg_path != 1) {
+    if (can_fuse && g_agg_path != 1) {
         g_launches = 0;
         if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
-        int rc2 = aggregate_fused(p, 1, &d_guide, &d_other, &d_cost, w, h, &dmin, s_begin, s_end, &d_keys,
+        int rc2 = aggregate_fused(g_agg_path, p, 1, &d_guide, &d_other, &d_cost, w, h, &dmin, s_begin, s_end, &d_keys,
                                &d_mean_u8, &d_agg, d_workspace, workspace_bytes, st, &g_launches);
         if (rc2) return rc2;
         if (g_timing) {
             SMX_HIP(hipEventRecord(g_ev1, st));
             g_ev_valid = true;
         }
-        g_last_path = g_agg_path >= 3 ? g_agg_path : 2;
         return SMX_OK;
     }
     g_last_path = 1;
@@ -354,7 +353,7 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = (int64_t)w * h;
     const int64_t vol = n * (s_end - s_begin);
-    if (v3_supported(p) && g_agg_path != 1) {
+    if (v4_supported(p) && g_agg_path != 1) {
         const uint8_t* guide[2] = {d_left, d_right};
         const uint8_t* other[2] = {d_right, d_left};
         const int dmin[2] = {dminl, dminr};
@@ -363,7 +362,7 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
         float* agg[2] = {d_agg, d_agg ? d_agg + vol : nullptr};
         g_launches = 0;
         if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
-        int rc2 = aggregate_fused(p, 2, guide, other, nullptr, w, h, dmin, s_begin, s_end, keys,
+        int rc2 = aggregate_fused(g_agg_path, p, 2, guide, other, nullptr, w, h, dmin, s_begin, s_end, keys,
                                d_mean_u8 ? mean : nullptr, d_agg ? agg : nullptr, d_workspace,
                                workspace_bytes, st, &g_launches);
         if (rc2) return rc2;
@@ -371,10 +370,9 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
             SMX_HIP(hipEventRecord(g_ev1, st));
             g_ev_valid = true;
         }
-        g_last_path = g_agg_path >= 3 ? g_agg_path : 2;
         return SMX_OK;
     }
-    if (g_agg_path == 2)
+    if (g_agg_path >= 2)
         return fail(SMX_E_ARG, "smx_dev_aggregate_wta_pair: fused path forced but radius > 9");
     int rc = smx_dev_aggregate_wta(p, d_left, d_right, nullptr, w, h, dminl, s_begin, s_end, d_keys,
                                    d_mean_u8, d_agg, d_workspace, workspace_bytes, stream);
@@ -535,6 +533,7 @@ int smx_filter(const smx_params* p, const uint8_t* image, int w, int h, uint8_t*
 struct smx_ctx {
     smx_params p;
     int w = 0, h = 0, size_d = 0, dev = -1;
+    int agg_path = 0;      // this context's aggregation path (smx_ctx_set_agg_path); starts as the creating thread's
     size_t n = 0, ws_bytes = 0;
     hipStream_t st = nullptr;
     // keys / best / dmap / mean: left view first, right view behind it (one buffer each)
@@ -551,6 +550,7 @@ int smx_create(const smx_params* p, int w, int h, int size_d, smx_ctx** out) {
     if (!c) return fail(SMX_E_HIP, "smx_create: out of host memory");
     struct Guard { smx_ctx* c; ~Guard() { delete c; } } guard{c};
     c->p = *p; c->w = w; c->h = h; c->size_d = size_d;
+    c->agg_path = g_agg_path;
     c->n = (size_t)w * h;
     const size_t n = c->n, fb = n * sizeof(float);
     SMX_HIP(hipGetDevice(&c->dev));
@@ -564,6 +564,13 @@ int smx_create(const smx_params* p, int w, int h, int size_d, smx_ctx** out) {
     SMX_HIP(c->ws.alloc(c->ws_bytes));
     guard.c = nullptr;
     *out = c;
+    return SMX_OK;
+}
+
+int smx_ctx_set_agg_path(smx_ctx* c, int path) {
+    SMX_ARG(c);
+    if (path < 0 || path > 5) return fail(SMX_E_ARG, "smx_ctx_set_agg_path: path must be 0 .. 5");
+    c->agg_path = path;
     return SMX_OK;
 }
 
@@ -608,7 +615,7 @@ int smx_ctx_stereo_pair(smx_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r
     }
     if ((rc = smx_dev_init_keys(keysL, 2 * nn, st))) return rc;
     // main.cu:133-134, both views per kernel launch
-    if (v3_supported(p) && g_agg_path != 1) {
+    if (v4_supported(p) && c->agg_path != 1) {
         const uint8_t* guide[2] = {dL, dR};
         const uint8_t* other[2] = {dR, dL};
         const float* cost[2] = {c->costL.as<float>(), c->costR.as<float>()};
@@ -617,11 +624,12 @@ int smx_ctx_stereo_pair(smx_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r
         uint8_t* mv[2] = {c->mean.as<uint8_t>(), c->mean.as<uint8_t>() + n};
         float* av[2] = {c->aggLR.as<float>(), want_agg ? c->aggLR.as<float>() + (size_t)size_d * n : nullptr};
         g_launches = 0;
-        if ((rc = aggregate_fused(p, 2, guide, other, want_cost ? cost : nullptr, w, h, dmin, 0, size_d, kv, mv,
+        if ((rc = aggregate_fused(c->agg_path, p, 2, guide, other, want_cost ? cost : nullptr, w, h, dmin, 0, size_d, kv, mv,
                                   want_agg ? av : nullptr, c->ws.p, c->ws_bytes, st, &g_launches)))
             return rc;
-        g_last_path = g_agg_path >= 3 ? g_agg_path : 2;
     } else {
+        const int saved = g_agg_path;
+        g_agg_path = 1;
         if ((rc = smx_dev_aggregate_wta(p, dL, dR, want_cost ? c->costL.as<float>() : nullptr, w, h, dminl, 0, size_d,
                                         keysL, c->mean.as<uint8_t>(), want_agg ? c->aggLR.as<float>() : nullptr, c->ws.p,
                                         c->ws_bytes, st)))
@@ -630,7 +638,8 @@ int smx_ctx_stereo_pair(smx_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r
                                         keysR, c->mean.as<uint8_t>() + n,
                                         want_agg ? c->aggLR.as<float>() + (size_t)size_d * n : nullptr, c->ws.p,
                                         c->ws_bytes, st)))
-            return rc;
+            { g_agg_path = saved; return rc; }
+        g_agg_path = saved;
     }
     // main.cu:112-118 presets, winning slices, main.cu:140-155
     if ((rc = smx_dev_finish_pair(p, keysL, w, h, dminl, dminr, dminl - 100, (float)dminl, bestL, mapL,

@@ -218,8 +218,15 @@ def test_pair_tsukuba_against_committed_outputs(tsukuba_gray, tsukuba_oracle, go
     _eq(r["meanl"], golden["image_mean_left"], "mean png")
 
 
+# what smx_last_agg_path() reports for a forced path: 2 = fused with the walker the call picks (comb walker 5 where
+# it applies -- radius 9, costs built from the images, default-like cost parameters -- else the ring walker 2),
+# 3 = ring walker forced, 5 = comb walker forced, 1 = multi-kernel, 4 = FAST
+_RAN = {0: (1, 2, 5), 1: (1,), 2: (2, 5), 3: (2,), 4: (4,), 5: (5,)}
+
+
 def _device_pair(Il, Ir, D, path=2, **kw):
-    """path: 2 = fused single-kernel aggregation (the default product path), 1 = multi-kernel path."""
+    """path: 2 = fused single-kernel aggregation (the default product path), 1 = multi-kernel path,
+    3 / 5 = fused with the ring / comb walker forced."""
     import torch
     from stereo_matching_cuda_amd.device import PairPipeline
     h, w = Il.shape
@@ -229,13 +236,13 @@ def _device_pair(Il, Ir, D, path=2, **kw):
     smx.lib().smx_set_agg_path(path)
     try:
         pipe.run(dl, dr)
-        assert path == 0 or smx.lib().smx_last_agg_path() == path
+        assert smx.lib().smx_last_agg_path() in _RAN[path]
     finally:
         smx.lib().smx_set_agg_path(0)
     return pipe.results()
 
 
-@pytest.mark.parametrize("path", [2, 1, 3])
+@pytest.mark.parametrize("path", [2, 1, 3, 5])
 def test_device_pipeline_tsukuba_fused_cost(tsukuba_gray, tsukuba_oracle, path):
     Il, Ir = tsukuba_gray
     r = _device_pair(Il, Ir, 16, path=path, dminl=-15, dminr=0, want_agg=True)
@@ -319,7 +326,7 @@ def test_default_path_is_the_fused_one(tsukuba_gray):
     Il, Ir = tsukuba_gray
     pipe = PairPipeline(384, 288, 16)
     pipe.run(torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda())
-    assert smx.lib().smx_last_agg_path() == 2
+    assert smx.lib().smx_last_agg_path() == 5      # the comb walker (smx_agg_v5.hip) at the reference's parameters
 
 
 def _geometry(radius):
@@ -328,16 +335,14 @@ def _geometry(radius):
     return ow.value, bh.value, tw.value
 
 
-def _ragged_shapes():
-    """Shapes aimed at the tile boundaries of the fused kernel, derived from its geometry constants
+def _ragged_shapes(OW, BH, dense):
+    """Shapes aimed at the tile boundaries of a fused walker, derived from its geometry constants
     (smx_agg_geometry): widths around multiples of the strip width OW (w % OW in {0, 1, OW-1}, and
     w + R crossing a strip count), heights around multiples of the band height BH (exact multi-band
     heights, one row more / less, heights whose lagged stage-2 / q rows need an extra band)."""
-    # literal copies of the library constants; test_ragged_shapes_match_the_library_geometry pins them
-    OW, BH = 64, 16
     ws = [2, OW - 1, OW, OW + 1, 2 * OW - 9, 2 * OW - 8, 2 * OW, 2 * OW + 1, 3 * OW - 1]
     hs = [1, BH - 1, BH, BH + 1, 2 * BH, 2 * BH + 1, 3 * BH - 18, 3 * BH - 9, 3 * BH, 4 * BH + 7]
-    shapes = [(2, 1, 2), (20, 20, 3), (19, 40, 4), (300, 200, 70)]
+    shapes = [(2, 1, 2), (20, 20, 3), (19, 40, 4), (300, 200, 70 if dense else 9)]
     for i, w in enumerate(ws):
         shapes.append((w, hs[i % len(hs)], 3 + i % 5))
     for i, h in enumerate(hs):
@@ -345,24 +350,63 @@ def _ragged_shapes():
     return sorted(set(shapes))
 
 
+# literal copies of the library constants; test_ragged_shapes_match_the_library_geometry pins them
+_RING = (64, 16)       # smx_agg_v4.hip: output columns per strip, rows per band
+_COMB = (285, 10)      # smx_agg_v5.hip
+
+
 def test_ragged_shapes_match_the_library_geometry():
-    assert _geometry(9) == (64, 16, 83)
-    assert _geometry(0) == (64, 16, 65)
+    assert _geometry(9) == (_COMB[0], _COMB[1], _COMB[0] + 19)
+    assert _geometry(0) == (_RING[0], _RING[1], _RING[0] + 1)        # the comb walker serves radius 9 only
+    smx.lib().smx_set_agg_path(3)
+    try:
+        assert _geometry(9) == (_RING[0], _RING[1], _RING[0] + 19)
+    finally:
+        smx.lib().smx_set_agg_path(0)
 
 
-@pytest.mark.parametrize("w,h,D", _ragged_shapes())
-def test_fused_path_small_and_ragged(orc, w, h, D):
-    """Strip / band / ring boundaries of the fused kernel (64 output columns per strip, 16-row bands,
-    36-row rings at the time of writing -- the shapes follow smx_agg_geometry), images smaller than
-    one tile, disparity ranges wider than the image."""
+@pytest.mark.parametrize("path,w,h,D", [(3,) + s for s in _ragged_shapes(*_RING, True)] +
+                         [(5,) + s for s in _ragged_shapes(*_COMB, False)])
+def test_fused_path_small_and_ragged(orc, path, w, h, D):
+    """Strip / band boundaries of both fused walkers (ring walker: 64 output columns per strip, 16-row bands,
+    36-row rings; comb walker: 285 columns, 10-row bands, 20-slot register rings -- the shapes follow
+    smx_agg_geometry), images smaller than one tile, disparity ranges wider than the image."""
     rng = np.random.default_rng(w * 7 + h * 3 + D)
     base = rng.integers(0, 256, size=(h, w + D), dtype=np.uint8)
     Il = np.ascontiguousarray(base[:, :w])
     Ir = np.ascontiguousarray(base[:, D // 2: D // 2 + w])
     want = orc.stereo_pair(Il, Ir, D, want_agg=True)
-    r = _device_pair(Il, Ir, D, want_agg=True)
+    r = _device_pair(Il, Ir, D, path=path, want_agg=True)
     for k in KEYS + ("aggl", "aggr"):
         _eq(r[k], want[k], k)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_comb_walker_fuzz(orc, seed):
+    """Seeded random shapes up to five strips wide through the comb walker (radius 9, reference parameters,
+    random d_lr and disparity ranges incl. ones that point outside the image) vs the oracle; every third
+    seed has flat regions: zero costs, exact ties, zero window sums."""
+    rng = np.random.default_rng(5000 + seed)
+    w = int(rng.integers(2, 1300))
+    h = int(rng.integers(1, 90))
+    D = int(rng.integers(1, 12))
+    p = smx.default_params()
+    p.d_lr = int(rng.integers(0, 3))
+    dminl = int(-rng.integers(0, 2 * D + 3))
+    dminr = int(rng.integers(-3, D + 3))
+    shift = int(rng.integers(0, max(1, min(D, w // 3))))
+    base = rng.integers(0, 256, size=(h, w + D + 8), dtype=np.uint8)
+    if seed % 3 == 0:
+        base = (base // 64 * 64).astype(np.uint8)
+    if seed % 5 == 4:
+        base[:] = 255                               # saturated: every cost is zero
+    Il = np.ascontiguousarray(base[:, :w])
+    Ir = np.ascontiguousarray(base[:, shift:shift + w])
+    po = orc.Params.from_buffer_copy(bytes(p))
+    want = orc.stereo_pair(Il, Ir, D, dminl=dminl, dminr=dminr, want_agg=True, params=po)
+    r = _device_pair(Il, Ir, D, path=5, dminl=dminl, dminr=dminr, want_agg=True, params=p)
+    for k in KEYS + ("aggl", "aggr"):
+        _eq(r[k], want[k], f"seed {seed} w={w} h={h} D={D} {k}")
 
 
 @pytest.mark.parametrize("radius,w,h", [(0, 128, 52), (0, 129, 53), (4, 64, 26), (4, 65, 78), (4, 192, 27), (4, 64, 16), (9, 130, 33), (1, 70, 48)])
