@@ -10,7 +10,7 @@ _SO = os.path.join(_HERE, "_build", "libsmx_oracle.so")
 
 __all__ = [
     "build", "lib", "Params", "gray", "xderiv", "cost_volume", "integral", "box_mean",
-    "guidance", "filter", "init_wta", "guided_filter", "detect_occlusion", "fill_occlusion",
+    "guidance", "filter", "init_wta", "guided_filter", "guided_filter_slices", "detect_occlusion", "fill_occlusion",
     "write_mat_u8", "stereo_pair", "pack_keys", "unpack_keys", "WTA_INIT_BITS", "KEY_IDENTITY",
 ]
 
@@ -140,6 +140,24 @@ def guided_filter(I, cost, dmin, best=None, dmap=None, s_begin=0, s_end=None, wa
                             _p(best, C.c_float), _p(dmap, C.c_float), _p(mean_u8, C.c_uint8),
                             _p(agg, C.c_float), w, h, dmin, s_begin, s_end)
     return best, dmap, mean_u8, agg
+
+
+def guided_filter_slices(I, other, dmin, s_begin, s_end, params=None):
+    """Slices [s_begin, s_end) of one view at full geometry without the rest of the volume: their cost planes
+    (d = dmin + s), aggregated planes and the packed WTA keys of the range from fresh presets.  Slices are
+    independent (guidedFilter.cu:171-238); orc_guided_filter indexes the volume by absolute slice, so the pointer
+    is shifted instead of materialising the whole volume (6.6 GB / 17 GB for BASELINE configs 3 / 5)."""
+    I, other = _u8(I), _u8(other)
+    h, w = I.shape
+    cost = cost_volume(I, other, s_end - s_begin, dmin + s_begin, params)
+    best, dmap = init_wta(h, w)
+    agg = np.empty((s_end - s_begin, h, w), np.float32)
+    base = cost.ctypes.data - s_begin * h * w * 4
+    lib().orc_guided_filter(C.byref(_params(params)), _p(I, C.c_uint8),
+                            C.cast(C.c_void_p(base), C.POINTER(C.c_float)), _p(best, C.c_float),
+                            _p(dmap, C.c_float), None, _p(agg, C.c_float), w, h, dmin, s_begin, s_end)
+    keys = pack_keys(best, (dmap - dmin).astype(np.int64))
+    return agg, keys
 
 
 def detect_occlusion(dL, dR, d_occlusion, params=None):

@@ -1311,7 +1311,9 @@ size_t v4_workspace_bytes(int w, int h, int nslices) {
     b += 2 * align_up(L.fg * 4, 256);                               // both image planes (single-view calls too)
     b += align_up(L.plane * 8, 256);                                // (mean_I, 1/(var+eps))
     b += 2 * align_up(L.plane * 4, 256);                            // guidance scratch: integrals of I, I*I
-    b += (size_t)nslices * align_up(L.plane * 4, 256);              // q
+    const size_t qp5 = (size_t)v5::strips(w) * h * v5::OWS;          // comb-ordered q plane of the comb walker
+    b += (size_t)nslices * align_up((L.plane > qp5 ? L.plane : qp5) * 4, 256);   // q
+    b += align_up((size_t)v5::strips(w) * h * v5::CLP * 12, 256) + 256;          // comb-ordered guidance planes
     const size_t hand5 = v5::sv_hand_floats(h);                    // the comb walker's records (smx_agg_v5.hip)
     b += align_up((size_t)nslices * (L.sv_hand > hand5 ? L.sv_hand : hand5) * 4, 256);
     b += v4_flag_bytes(L, 2 * nslices);                             // control block (shared by both views; K of either walker <= L.K)
@@ -1414,12 +1416,23 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     v4::f2* gpair[2];
     for (int i = 0; i < 2; ++i) FG[i] = (v4::fg_t*)carve(L.fg * 4);
     for (int v = 0; v < nviews; ++v) gpair[v] = (v4::f2*)carve(L.plane * 8);
+    // comb-ordered guidance planes of the comb walker (smx_agg_v5.h): [K][h][CLP] per view
+    v4::f2* g1p[2] = {nullptr, nullptr};
+    unsigned* i2p[2] = {nullptr, nullptr};
+    const size_t permn = (size_t)v5::strips(w) * h * v5::CLP;
+    if (use_v5)
+        for (int v = 0; v < nviews; ++v) {
+            g1p[v] = (v4::f2*)carve(permn * 8);
+            i2p[v] = (unsigned*)carve(permn * 4);
+        }
     const char* const fix_end = base;       // image planes + guidance planes: the comb walker addresses them through one descriptor
     for (int i = 0; i < 2 * nviews; ++i) gs[i] = (float*)carve(L.plane * 4);
     const int total = s_end - s_begin;
     // per slice-view: q plane (unless the caller's volume is written directly) + records + flags
     const bool own_q = !(d_agg && d_agg[0]);
-    const size_t per_sv = (own_q ? align_up(L.plane * 4, 256) : 0) + L.sv_hand * 4 +
+    // (the comb walker's own q planes are comb-ordered: K * OWS >= w columns per row)
+    const size_t qplane = use_v5 && own_q ? (size_t)L.K * h * v5::OWS : L.plane;
+    const size_t per_sv = (own_q ? align_up(qplane * 4, 256) : 0) + L.sv_hand * 4 +
                           (size_t)L.K * sizeof(unsigned);
     size_t fit = avail > 8 * 256 + V4_CTRL_BYTES ? (avail - 8 * 256 - V4_CTRL_BYTES) / (per_sv * nviews) : 0;
     if (oom || (fit < 1 && total > 0))
@@ -1430,7 +1443,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     const int nsv_max = chunk * nviews;
     float* qbuf[2] = {nullptr, nullptr};
     if (own_q)
-        for (int v = 0; v < nviews; ++v) qbuf[v] = (float*)carve((size_t)chunk * align_up(L.plane * 4, 256));
+        for (int v = 0; v < nviews; ++v) qbuf[v] = (float*)carve((size_t)chunk * align_up(qplane * 4, 256));
     v4::f2* hand = (v4::f2*)carve((size_t)nsv_max * L.sv_hand * 4);
     char* ctrl = (char*)carve(v4_flag_bytes(L, nsv_max));
     if (oom) return fail(SMX_E_WS, "aggregate_v4: workspace carve overflow");
@@ -1475,6 +1488,10 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         hipLaunchKernelGGL(v4::k_v4_guid_finish, dim3(cdivu4(w, 256), h, nviews), dim3(256), 0, st, ga, w, h, R, p->eps);
         SMX_HIP(hipGetLastError());
         nl += 3;
+        if (use_v5) {
+            if ((rc = v5_perm_launch(nviews, gpair, FG, g1p, i2p, w, h, st))) return rc;
+            ++nl;
+        }
     }
 
     v4::Args a0;
@@ -1491,7 +1508,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         v4::WtaArgs wa;
         for (int v = 0; v < 2; ++v) {
             const int vv = v < nviews ? v : 0;
-            float* qv = own_q ? qbuf[vv] : d_agg[vv] + (size_t)(s0 - s_begin) * L.plane;
+            float* qv = own_q ? qbuf[vv] : d_agg[vv] + (size_t)(s0 - s_begin) * L.plane;   // (own planes: `qplane` floats apart)
             if (v < nviews) {
                 a.v[v].q = qv;
                 a.v[v].d0 = dmin[v] + s0;
@@ -1514,7 +1531,8 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             for (int v = 0; v < 2; ++v) {
                 const int vv = v < nviews ? v : 0;
                 b.o_fg[v] = (unsigned)((const char*)FG[v] - b.fix);
-                b.o_guid[v] = (unsigned)((const char*)gpair[vv] - b.fix);
+                b.o_g1p[v] = (unsigned)((const char*)g1p[vv] - b.fix);
+                b.o_i2p[v] = (unsigned)((const char*)i2p[vv] - b.fix);
                 b.q[v] = a.v[vv].q;
                 b.d0[v] = a.v[vv].d0;
             }
@@ -1522,13 +1540,17 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             b.nslices = a.nslices; b.nsv = a.nsv; b.nitems = a.nitems;
             b.hand = (float*)hand; b.flags = a.flags; b.ticket = a.ticket; b.status = a.status;
             b.cc = a.cc;
+            b.qperm = own_q ? 1 : 0;
+            b.q_plane = qplane;
             rc = v5_launch(b, st);
         } else if (fast) rc = use_cost ? launch_walk4<v4::SRC_COST, true>(a, st) : launch_walk4<v4::SRC_IMG, true>(a, st);
         else rc = use_cost ? launch_walk4<v4::SRC_COST, false>(a, st) : launch_walk4<v4::SRC_IMG, false>(a, st);
         if (rc) return rc;
         bool al8 = L.plane % 2 == 0;
         for (int v = 0; v < nviews; ++v) al8 = al8 && ((uintptr_t)wa.q[v] & 7) == 0;
-        if (al8)
+        if (use_v5 && own_q) {
+            if ((rc = v5_wta_launch(nviews, wa.q, wa.keys, w, h, cnt, s0, st))) return rc;
+        } else if (al8)
             hipLaunchKernelGGL(v4::k_v4_wta2, dim3(cdivu4((int64_t)L.plane, 512), nviews), dim3(256), 0, st, wa,
                                L.plane, cnt, s0);
         else

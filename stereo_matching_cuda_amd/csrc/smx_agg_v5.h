@@ -10,6 +10,7 @@ constexpr int OWS = 285;                // output columns per strip (19 combs x 
 constexpr int BH = 10;                  // band height
 constexpr int REC_U = 105;              // 16-byte units per hand-off record
 constexpr int WG_PER_CU = 2;
+constexpr int CLP = 320;                // comb lanes per stage and strip (5 waves; 304 in use)
 
 struct Args {
     // the fixed part of the workspace: both image planes [h][w + 2 PADX] of k_v4_prep and the guidance planes
@@ -17,8 +18,15 @@ struct Args {
     const char* fix;
     size_t fix_bytes;
     unsigned o_fg[2];     // byte offset of view v's image plane (the other view's is o_fg[v ^ 1])
-    unsigned o_guid[2];   // byte offset of view v's guidance plane
-    float* q[2];          // out: [slice][h][w] per view
+    // comb-ordered copies (k_v5_perm): what a comb lane cl = 16 rho + il of strip k needs in row y sits at
+    // [k][y][cl], so that a wave's guidance load is one contiguous run instead of 16 clusters of 4 columns
+    unsigned o_g1p[2];    // float2 [K][h][CLP]: (mean_I, 1/(var_I + eps)) at the a/b column 285 k - 10 + 19 il + rho
+    unsigned o_i2p[2];    // u32    [K][h][CLP]: raw (value, gradient) halves at the q column 285 k - 19 + 19 il + rho
+    // out, per view: qperm != 0: comb-ordered scratch [slice][K][h][OWS], column 285 k + 19 (il-1) + rho at
+    // [15 rho + il - 1] (a wave stores 240 contiguous bytes; read back by k_v5_wta); else the caller's [slice][h][w]
+    float* q[2];
+    int qperm;
+    size_t q_plane;       // floats per slice of q
     int d0[2];            // disparity of local slice 0 per view
     int w, h, K, NI, nslices, nsv, nitems;
     float* hand;          // hand-off records [parity][sv][iteration][REC_U x 4 floats]
@@ -39,5 +47,11 @@ inline size_t sv_hand_floats(int h) { return (size_t)2 * bands(h) * REC_U * 4; }
 // term >= 2^-60, eps >= 1
 bool v5_supported(const smx_params* p);
 int v5_launch(const v5::Args& a, hipStream_t st);
+// comb-ordered guidance planes of one call: G (mean_I, 1/(var+eps)) [h][w] and the image planes FG -> g1p, i2p
+int v5_perm_launch(int nviews, const aggdev::f2* const* G, const aggdev::fg_t* const* FG, aggdev::f2* const* g1p,
+                   unsigned* const* i2p, int w, int h, hipStream_t st);
+// packed-key WTA over `count` comb-ordered q planes (slice slice0 ..) of `nviews` views -> keys [h][w]
+int v5_wta_launch(int nviews, const float* const* q, int64_t* const* keys, int w, int h, int count, int slice0,
+                  hipStream_t st);
 
 }  // namespace smx

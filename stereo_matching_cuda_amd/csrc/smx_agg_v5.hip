@@ -72,6 +72,28 @@ static_assert(P1 % 64 == 0 && P1 >= SW && RS >= P1 + SW && RS % 4 == 0, "tile ro
 constexpr int NHU = BH * 10, NCU = BH / 2;
 static_assert(REC_U == NHU + NCU, "record layout");
 
+// Diagnostic build only (-DSMX_V5_STAMPS=<item>): every wave of one work item records the shader clock at the
+// start and end of its work in the W, R and X phases (the gaps are barrier waits); the product build has no stamp.
+#ifdef SMX_V5_STAMPS
+constexpr int STAMP_W = 6;
+constexpr int STAMP_SLOTS = STAMP_W * 48;
+__device__ unsigned long long g_stamps[10 * STAMP_SLOTS];
+#define V5_STAMP(n)                                                                          \
+    do {                                                                                     \
+        if (item == SMX_V5_STAMPS && lane == 0 && i * STAMP_W + (n) < STAMP_SLOTS)            \
+            g_stamps[wave * STAMP_SLOTS + i * STAMP_W + (n)] = __builtin_amdgcn_s_memtime();  \
+    } while (0)
+#else
+#define V5_STAMP(n) ((void)0)
+#endif
+// Diagnostic build only (-DSMX_V5_WHATIF=<bits>): leaves parts of the work out (WRONG results) to see what the
+// kernel time is sensitive to.  1: no row scans; 2: no cost evaluation; 4: no stage-1 comb rows; 8: no stage-2 comb
+// rows; 16: no q stores; 32: no guidance loads; 64: no hand-off (every strip like strip 0); 128: no input loads
+#ifndef SMX_V5_WHATIF
+#define SMX_V5_WHATIF 0
+#endif
+constexpr int WHATIF = SMX_V5_WHATIF;
+
 #ifdef SMX_V5_DUMP
 // Diagnostic build only: tile 1 (current buffer), tile 2 and the comb registers of one item behind the barrier that
 // ends phase SMX_V5_DUMP_PH (0 W, 1 R, 2 X) of iteration SMX_V5_DUMP_IT
@@ -91,6 +113,30 @@ __device__ __forceinline__ float add_left(float own, float left) {      // own +
     float d;
     asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(left), "v"(own));
     return d;
+}
+
+// cost_pair of smx_agg_dev.h with the two truncations as v_min_f32 |d|, <scalar threshold>: the thresholds stay in
+// SGPRs (the generic form canonicalises them into VGPRs that then live through the whole kernel)
+__device__ __forceinline__ f2 cost_pair_s(fg_t q1, fg_t q2, const CostConst& cc) {
+    const f2 v1 = {(float)q1.x, (float)q1.y}, v2 = {(float)q2.x, (float)q2.y};
+    const f2 d = v1 - v2;
+    f2 m;
+    asm("v_min_f32 %0, |%1|, %2" : "=v"(m.x) : "v"(d.x), "s"(cc.th_color));
+    asm("v_min_f32 %0, |%1|, %2" : "=v"(m.y) : "v"(d.y), "s"(cc.th_grad));
+    const f2 xz = (f2){cc.oma, cc.alpha} * m;
+    f2 r;
+    r.x = xz.x + xz.y;
+    r.y = v1.x * r.x;
+    return r;
+}
+// x / area for both components of a cell with ca = (RN(1/area), area) in ONE register pair: div_small_int2 with the
+// operands broadcast by op_sel (low half = 1/area, high half = area) instead of two ready-made pairs
+__device__ __forceinline__ f2 div_ca(f2 x, f2 ca) {
+    f2 q, e, m;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(q) : "v"(x), "v"(ca));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(e) : "v"(q), "v"(ca), "v"(x));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(m) : "v"(e), "v"(ca), "v"(q));
+    return m;
 }
 
 // a cell's (first, second) component of a tile row (the compiler forms ds_read2st64_b32 / ds_write2st64_b32:
@@ -127,6 +173,18 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
     constexpr int NCT = NT - 64;                                    // 576 cost threads (waves 1..9)
     constexpr int NQB = BH * NQROW - NCT;                           // 184 quads left for round B = 368 pairs
     static_assert(NQB > 0 && 2 * NQB <= NCT, "two rounds cover the band");
+    // stage-1 input units of this thread (waves 1..9): round A one quad (tile row a_row, columns a_col ..+3),
+    // round B one pair (b_row, b_col, b_col+1); packed into one register: a_col | a_row << 9 | b_col << 13 |
+    // b_row << 22 | b_on << 26
+    unsigned cgeo;
+    {
+        const int ct = max(tid - 64, 0);
+        const int a_row = ct / NQROW, a_col = (ct - a_row * NQROW) * 4;
+        const int u = NCT + (ct >> 1), ur = u / NQROW;
+        const int b_row = min(ur, BH - 1), b_col = (u - ur * NQROW) * 4 + 2 * (ct & 1);
+        cgeo = (unsigned)a_col | (unsigned)a_row << 9 | (unsigned)b_col << 13 | (unsigned)b_row << 22 |
+               (ct < 2 * NQB ? 1u << 26 : 0u);
+    }
 
     if (tid == 0) s_item = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
@@ -139,20 +197,23 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
         const int slice = sv - view * A.nslices;
         const int base1 = OWS * k - 1;          // image column of tile-1 column 0
         const int base2 = OWS * k - R - 1;      // image column of tile-2 column 0 (= a/b column of the same comb lane)
-        const bool pred = k > 0, succ = k + 1 < K;
+        const bool pred = k > 0 && !(WHATIF & 64), succ = k + 1 < K && !(WHATIF & 64);
         const int d = A.d0[view] + slice;
         unsigned* const myflag = A.flags + (size_t)sv * K + k;
         // Buffer descriptors: ONE over the fixed part of the workspace (both image planes, the guidance plane: the
         // plane is chosen by a scalar offset), one over the hand-off records, one over this slice's q plane.
         const unsigned fgw4 = ((unsigned)w + 2u * PADX) * 4u, w4 = (unsigned)w * 4u;
-        const size_t plane = (size_t)h * w;
         const rsrc_t r_fix = mk_rsrc(A.fix, A.fix_bytes);
-        const int o_fg1 = (int)A.o_fg[view], o_fg2 = (int)A.o_fg[view ^ 1], o_g = (int)A.o_guid[view];
+        const int o_fg1 = (int)A.o_fg[view], o_fg2 = (int)A.o_fg[view ^ 1];
+        // this strip's rows of the comb-ordered guidance planes
+        const int o_g1p = (int)(A.o_g1p[view] + (unsigned)k * (unsigned)h * (CLP * 8u)), o_i2p = (int)(A.o_i2p[view] + (unsigned)k * (unsigned)h * (CLP * 4u));
         const unsigned recb = (unsigned)NI * REC_U * 16u;        // bytes per (parity, slice-view)
         const rsrc_t r_hand = mk_rsrc(A.hand, (size_t)2 * nsv * recb);
         const int o_in = (int)((((unsigned)(k - 1) & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
         const int o_out = (int)((((unsigned)k & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
-        const rsrc_t r_q = mk_rsrc(A.q[view] + (size_t)slice * plane, plane * 4);
+        const rsrc_t r_q = mk_rsrc(A.q[view] + (size_t)slice * A.q_plane, A.q_plane * 4);
+        // q rows: comb-ordered scratch (row y of this strip at (k h + y) * OWS) or the caller's [h][w]
+        const int q_pitch = A.qperm ? OWS * 4 : (int)w4, q_row0 = A.qperm ? k * h * (OWS * 4) : 0;
 
         // the strip has columns outside the image (virtual: -0)
         const bool xedge = base1 < 0 || base1 + SW > w;
@@ -162,7 +223,8 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
         const int jt = comb_jt();                                   // tile column
         int xw;                                                     // window width of this lane's output column
         float rcp_i;                                                // 1 / (19 xw): interior rows
-        unsigned vo;                                                // byte offset of the output column: guidance pair (stage 1), q (stage 2; the guidance image value sits PADX further)
+        unsigned vo;                                                // stage 2: byte offset of the q column in a q row (stage 1: unused)
+        unsigned vg;                                                // byte offset of this lane in a row of the comb-ordered guidance plane
         bool col_ok;
         {
             const int il = lane & 15;
@@ -170,9 +232,18 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
             col_ok = comb_rho() < HW && xo >= 0 && xo < w && (!ST2 || il >= 1);
             xw = col_ok ? min(w - 1, xo + R) - max(-1, xo - R - 1) : 1;
             rcp_i = rcp_s[HW * xw];
-            vo = col_ok ? (unsigned)xo * (ST2 ? 4u : 8u) : OOB;
+            {
+                const int cl = comb_rho() * 16 + il;
+                vg = (unsigned)cl * (ST2 ? 4u : 8u);
+                vo = !col_ok ? OOB : (A.qperm ? (unsigned)(15 * comb_rho() + il - 1) * 4u : (unsigned)xo * 4u);
+            }
         }
-        const f2 area2_i = {(float)(HW * xw), (float)(HW * xw)}, rcp2_i = {rcp_i, rcp_i};
+        const f2 ca_i = {rcp_i, (float)(HW * xw)};                       // interior rows: (1/area, area)
+        const uint64_t okmask = __builtin_amdgcn_ballot_w64(col_ok);     // lanes with an output
+        // stage 1: tile-2 column this lane's a_k, b_k go to -- its own tile column, or a padding column of the row when
+        // that column is the left neighbour's halo (lane 0 of a comb of a strip with a neighbour) or the lane idles
+        const int jw = (comb_rho() < HW && !(pred && (lane & 15) == 0)) ? jt : SW + (lane & 15);
+        static_assert(SW + 16 <= P1 && P1 + SW + 16 <= RS, "padding columns behind both planes of a tile row");
 
         // ---- register state ------------------------------------------------------------------------------------
         f2 ring[RD];                         // ring[y mod RD] = S[y] of this lane's column; the slot of row y-1 is the running sum
@@ -181,15 +252,10 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
         ring[ST2 ? 10 : RD - 1] = NZ2;   // the slot in front of the first row (stage 1: row 0; stage 2: row -9)
         // (arrays of the other role shrink to one element: the two roles are separate instantiations, so that no
         // register carries state of the other role around the band loop)
-        f2 abreg[ST2 ? 1 : BH];              // stage 1: a_k, b_k of this lane's rows, written to tile 2 in the next W phase
-#pragma unroll
-        for (int t = 0; t < (ST2 ? 1 : BH); ++t) abreg[t] = NZ2;
-        constexpr int GPF = 4;               // guidance rows in flight per lane
+        constexpr int GPF = ST2 ? 4 : 2;     // guidance rows in flight per lane
         f2 gq[ST2 ? 1 : GPF];                // stage 1: (mean_I, 1/(var+eps))
         unsigned gI[ST2 ? GPF : 1];          // stage 2: raw (value, gradient) halves of the guidance image
-        u4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};   // round-A raw quads of the two images
-        u2 pa = {0, 0}, pb = {0, 0};               // round-B raw pairs
-        f4 hreg = {0, 0, 0, 0};              // (stage-2 role) this thread's unit of the left neighbour's next record
+        f4 hreg = {0, 0, 0, 0};              // (stage-1 role, threads 0 .. REC_U-1) this thread's unit of the left neighbour's next record
         bool have_pref = false;
         unsigned seen = 0;
 
@@ -197,56 +263,64 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
         // byte offsets in the two image planes without the band term
         struct CostGeo { int a_row, a_col, b_row, b_col; bool b_on; };
         auto cost_geo = [&]() {
+            // (opaque: the unpacked fields and everything derived from them -- plane offsets, tile offsets -- are
+            // re-derived where they are used instead of being hoisted out of the band loop into long-lived registers)
             CostGeo g;
-            const int ct = max(opaque(tid) - 64, 0);
-            g.a_row = ct / NQROW;
-            g.a_col = (ct - g.a_row * NQROW) * 4;
-            const int u = NCT + (ct >> 1), ur = u / NQROW;
-            g.b_row = min(ur, BH - 1);
-            g.b_col = (u - ur * NQROW) * 4 + 2 * (ct & 1);
-            g.b_on = ct < 2 * NQB;
+            const unsigned cg = (unsigned)opaque((int)cgeo);
+            g.a_col = (int)(cg & 511u);
+            g.a_row = (int)((cg >> 9) & 15u);
+            g.b_col = (int)((cg >> 13) & 511u);
+            g.b_row = (int)((cg >> 22) & 15u);
+            g.b_on = (cg >> 26) != 0;
             return g;
         };
-        // loads of the stage-1 inputs of band ib (rows clamped into the image: every load is issued)
+        // loads of the stage-1 inputs of band ib (rows clamped into the image: every load is issued): round-A raw quads
+        // and round-B raw pairs of the two images.  Locals of the phase that evaluates them: no register carries them on.
+        struct Raw { u4 ra, rb; u2 pa, pb; };
         auto issue_cost = [&](int ib) {
-            if (wave == 0) return;
+            Raw r;
             const CostGeo g = cost_geo();
             auto off = [&](int row, int col, int dd) {
                 const int y = min(BH * ib + row, h - 1);
                 return (unsigned)(min(max(base1 + col + dd, -PADX), w) + PADX) * 4u + (unsigned)y * fgw4;
             };
-            ra = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(g.a_row, g.a_col, 0), o_fg1, 0);
-            rb = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(g.a_row, g.a_col, d), o_fg2, 0);
-            pa = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)off(g.b_row, g.b_col, 0), o_fg1, 0);
-            pb = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)off(g.b_row, g.b_col, d), o_fg2, 0);
+            r.ra = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(g.a_row, g.a_col, 0), o_fg1, 0);
+            r.rb = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(g.a_row, g.a_col, d), o_fg2, 0);
+            r.pa = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)off(g.b_row, g.b_col, 0), o_fg1, 0);
+            r.pb = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)off(g.b_row, g.b_col, d), o_fg2, 0);
+            return r;
         };
         // raw -> (p, I p) -> tile 1 buffer `dst` (band ib); cells outside the image are -0
-        auto eval_cost = [&](int ib, float* dst) {
-            if (wave == 0) return;
+        auto eval_cost = [&](int ib, float* dst, const Raw& rw) {
+            const u4 ra = rw.ra, rb = rw.rb;
+            const u2 pa = rw.pa, pb = rw.pb;
             const CostGeo g = cost_geo();
             const bool edge = xedge || BH * ib + BH > h;
             {
                 const unsigned r1[4] = {ra.x, ra.y, ra.z, ra.w}, r2[4] = {rb.x, rb.y, rb.z, rb.w};
-                f4 px, py;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f2 v = cost_pair(__builtin_bit_cast(fg_t, r1[j]), __builtin_bit_cast(fg_t, r2[j]), cc);
-                    if (edge) {
-                        const int c = base1 + g.a_col + j;
-                        if (!(c >= 0 && c < w && BH * ib + g.a_row < h)) v = NZ2;
-                    }
-                    px[j] = v.x; py[j] = v.y;
-                }
                 float* p = dst + g.a_row * RS + g.a_col;
-                *(f4*)p = px;
-                *(f4*)(p + P1) = py;
+#pragma unroll
+                for (int jj = 0; jj < 4; jj += 2) {
+                    f2 px, py;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f2 v = cost_pair_s(__builtin_bit_cast(fg_t, r1[jj + j]), __builtin_bit_cast(fg_t, r2[jj + j]), cc);
+                        if (edge) {
+                            const int c = base1 + g.a_col + jj + j;
+                            if (!(c >= 0 && c < w && BH * ib + g.a_row < h)) v = NZ2;
+                        }
+                        px[j] = v.x; py[j] = v.y;
+                    }
+                    *(f2*)(p + jj) = px;
+                    *(f2*)(p + P1 + jj) = py;
+                }
             }
             if (g.b_on) {
                 const unsigned r1[2] = {pa.x, pa.y}, r2[2] = {pb.x, pb.y};
                 f2 px, py;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    f2 v = cost_pair(__builtin_bit_cast(fg_t, r1[j]), __builtin_bit_cast(fg_t, r2[j]), cc);
+                    f2 v = cost_pair_s(__builtin_bit_cast(fg_t, r1[j]), __builtin_bit_cast(fg_t, r2[j]), cc);
                     if (edge) {
                         const int c = base1 + g.b_col + j;
                         if (!(c >= 0 && c < w && BH * ib + g.b_row < h)) v = NZ2;
@@ -261,17 +335,18 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
         // guidance of output row yrow -> slot (rows clamped into the image: every load is issued)
         // (the rows an interior band asks for all exist: no clamp)
         auto issue_guid = [&](int slot, int yrow, bool clamp) {
+            if (WHATIF & 32) return;
             const int y = clamp ? min(max(yrow, 0), h - 1) : yrow;
             if constexpr (!ST2) {
-                const u2 g = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)vo, o_g + y * (int)(2u * w4), 0);
+                const u2 g = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)vg, o_g1p + y * (CLP * 8), 0);
                 gq[slot] = __builtin_bit_cast(f2, g);
             } else {
-                gI[slot] = ldu(r_fix, vo + 4u * PADX, o_fg1 + y * (int)fgw4);
+                gI[slot] = ldu(r_fix, vg, o_i2p + y * (CLP * 4));
             }
         };
 
         // hand-off unit of this thread (waves 5..): index hq < REC_U; halo units: row, first of its two columns
-        auto hu_idx = [&]() { return opaque(tid) - 64 * NS1; };
+        auto hu_idx = [&]() { return ST2 ? opaque(tid) - 64 * NS1 : opaque(tid); };
         auto fetch_rec = [&](int rec) {
             const int hq = hu_idx();
             hreg = ld16_sc1(r_hand, (unsigned)(o_in + rec * REC_U * 16) + (hq >= 0 && hq < REC_U ? (unsigned)hq * 16u : 0u));
@@ -305,7 +380,7 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
             const bool keep = sc_st == 1 && pred;
             float acc = (sc_st == 0 && pred) ? cin1[sc_row][sc_comp] : -0.0f;
             f4* const r4 = (f4*)row;
-            constexpr int NG = SW / 4, PF = 6;
+            constexpr int NG = SW / 4, PF = 4;
             f4 v[PF];
 #pragma unroll
             for (int g = 0; g < PF; ++g) v[g] = r4[g];
@@ -324,6 +399,7 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
                 r4[g] = x;
             }
             // groups 5 .. 75: PF groups of reads ahead of the dependent adds (past the end they re-read the last group)
+            f4 xo[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
             for (int g0 = 5; g0 < NG; g0 += PF) {
 #pragma unroll
                 for (int u = 0; u < PF; ++u) {
@@ -331,12 +407,15 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
                     if (g < NG) {
                         const f4 in = v[(5 + u) % PF];
                         v[(5 + u) % PF] = r4[min(g + PF, NG - 1)];
-                        f4 x;
+                        // the sums of two consecutive groups live in different registers: the adds of a group then do not
+                        // wait until the 16-byte store of the previous one has read its four source registers
+                        f4& x = xo[u & 1];
                         acc = in.x + acc; x.x = acc;
                         acc = in.y + acc; x.y = acc;
                         acc = in.z + acc; x.z = acc;
                         acc = in.w + acc; x.w = acc;
                         r4[g] = x;
+                        asm volatile("" :: "v"(xo[(u & 1) ^ 1]));
                     }
                 }
             }
@@ -353,25 +432,16 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
         u.x = add_left(u.x, ring[SL01].x);                     \
         u.y = add_left(u.y, ring[SL01].y);                     \
     } while (0)
-        // window area of output row y and 1/area for this lane, as pairs for the packed division (border bands:
-        // clipped window height, table look-up)
-        auto area_of = [&](int y, auto BORDERc, f2& area2, f2& rcp2) {
+        // (1/area, area) of output row y for this lane (border bands: clipped window height, table look-up)
+        auto area_of = [&](int y, auto BORDERc) {
             if constexpr (decltype(BORDERc)::value) {
                 const int yc = min(max(y, 0), h - 1);
                 const int yh = min(h - 1, yc + R) - max(-1, yc - R - 1);
                 const int ai = xw * yh;
-                const float a = (float)ai, r = rcp_s[ai];
-                area2 = (f2){a, a};
-                rcp2 = (f2){r, r};
+                return (f2){rcp_s[ai], (float)ai};
             } else {
-                area2 = area2_i;
-                rcp2 = rcp2_i;
+                return ca_i;
             }
-        };
-        auto div2 = [&](f2 x, f2 d2, f2 r2) {           // div_small_int2 with ready-made pairs
-            f2 q = x * r2;
-            f2 e = __builtin_elementwise_fma(-q, d2, x);
-            return __builtin_elementwise_fma(e, r2, q);
         };
 
         // One comb row of stage 1: T = row of the band, N = T + 10 * (band parity) = ring slot of its image row.
@@ -384,55 +454,56 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
             ring[SL] = rv + ring[SLP];                     // colSum integral.cu:124-128
             f2 u;
             V5_BOX(u, SL, SL01);
-            f2 area2, rcp2;
-            area_of(BH * i - R + T, BORDERc, area2, rcp2);
-            const f2 m = div2(u, area2, rcp2);             // (mean_p, mean_Ip); no window sum of p, I p can be tiny (smx_agg_v5.h)
+            const f2 m = div_ca(u, area_of(BH * i - R + T, BORDERc));   // (mean_p, mean_Ip); no window sum of p, I p can be tiny (smx_agg_v5.h)
             const f2 g = gq[N % GPF];
             // compute_ak_and_bk guidedFilter.cu:345-354
             const float mm = g.x * m.x;
             const float ak = 1.0f * (m.y - mm) * g.y;
             const float mb2 = 1.0f * g.x * ak;
             const float bk = 1.0f * m.x - mb2;
-            abreg[T] = (f2){ak, bk};
+            // a/b row 10 i - 9 + T -> tile 2 (scanned in R(i+1)); rows / columns outside the image: -0
+            f2 ab = {ak, bk};
+            if (BORDER || xedge) {
+                const int ya = BH * i - R + T;
+                if (!(col_ok && ya >= 0 && ya < h)) ab = NZ2;
+            }
+            tile_wr(tile2 + T * RS + jw, ab);
             // the guidance of the row GPF rows further down (next band: its first rows)
             issue_guid(N % GPF, BH * i - R + T + GPF, BORDER);
             rv = rvn;
             __builtin_amdgcn_sched_barrier(0);
         };
         // one comb row of stage 2 (a/b band i-1): ring slot of a/b row 10 (i-1) - 9 + T
-        auto row2 = [&](auto Nc, auto BORDERc, int i, f2& rv) {
+        auto row2 = [&](auto Nc, auto BORDERc, int i, const f2 (&r2)[BH]) {
             constexpr int N = decltype(Nc)::value, T = N % BH, PAR = N / BH;
             constexpr int SL = (BH * (PAR ^ 1) + T + 11) % RD, SL01 = (SL + 1) % RD, SLP = (SL + RD - 1) % RD;
             constexpr bool BORDER = decltype(BORDERc)::value;
-            const f2 rvn = tile_rd(tile2 + (T + 1 < BH ? T + 1 : T) * RS + jt);
-            ring[SL] = rv + ring[SLP];
+            ring[SL] = r2[T] + ring[SLP];
             f2 u;
             V5_BOX(u, SL, SL01);
             const int yq = BH * (i - 1) - 2 * R + T;
-            f2 area2, rcp2;
-            area_of(yq, BORDERc, area2, rcp2);
-            f2 m = div2(u, area2, rcp2);
+            const f2 ca = area_of(yq, BORDERc);
+            f2 m = div_ca(u, ca);
             // tiny (or zero) window sums of a, b take the true division (wave-uniform, rare); lanes without an
             // output do not vote
-            const float amin = fminf(fabsf(u.x), fabsf(u.y));
-            if (__any(col_ok && !(amin >= 0x1p-100f))) {
+            float amin;
+            asm("v_min_f32 %0, |%1|, |%2|" : "=v"(amin) : "v"(u.x), "v"(u.y));
+            if ((__builtin_amdgcn_ballot_w64(!(amin >= 0x1p-100f)) & okmask) != 0) {
                 asm volatile("; exact-division slow path");
-                m.x = 1.0f * u.x / area2.x;
-                m.y = 1.0f * u.y / area2.x;
+                m.x = 1.0f * u.x / ca.y;
+                m.y = 1.0f * u.y / ca.y;
             }
             const float Iv = (float)__builtin_bit_cast(fg_t, gI[N % GPF]).x;
             const float tq = m.x * Iv;                     // compute_q guidedFilter.cu:363-369
             const float qv = tq + m.y;
-            if (!BORDER || (yq >= 0 && yq < h))
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qv), r_q, (int)vo, yq * (int)w4, AUX_NT);
+            if (!(WHATIF & 16) && (!BORDER || (yq >= 0 && yq < h)))
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qv), r_q, (int)vo, q_row0 + yq * q_pitch, AUX_NT);
             issue_guid(N % GPF, yq + GPF, BORDER);
-            rv = rvn;
             __builtin_amdgcn_sched_barrier(0);
         };
 
         // ===================================== the band loop ==============================================
         // prologue: stage-1 inputs of band 0 -> tile 1[0]; guidance of the first rows; the left neighbour's record 0
-        issue_cost(0);
         // (stage 2 starts at i = 1 with comb rows N = 10 .. 13: slots 2, 3, 0, 1)
         if constexpr (ST2) {
 #pragma unroll
@@ -446,60 +517,37 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
             wg_barrier();
             seen = s_seen;
         }
-        if constexpr (ST2) fetch_rec(0);
+        if constexpr (!ST2) fetch_rec(0);
         have_pref = pred;
-        eval_cost(0, tile1[0]);
+        if (wave != 0) {
+            const Raw rw = issue_cost(0);
+            eval_cost(0, tile1[0], rw);
+        }
+
+        // hand-in of record `rec` (stage-1 role, strips with a left neighbour): stage-2 halo columns -> tile 2 (scanned
+        // around in R(rec)), stage-1 row carries -> LDS
+        auto hand_in = [&](int rec) {
+            const int hq = hu_idx();
+            if (hq >= 0 && hq < NHU) {
+                if (rec >= 1) {
+                    const int t = hq / 10, j = (hq - 10 * t) * 2;
+                    float* dst = tile2 + t * RS + j;
+                    dst[0] = hreg.x;
+                    dst[P1] = hreg.y;
+                    if (j + 1 < HW) { dst[1] = hreg.z; dst[P1 + 1] = hreg.w; }
+                }
+            } else if (hq >= NHU && hq < REC_U) {
+                const int tp = hq - NHU;
+                cin1[2 * tp][0] = hreg.x; cin1[2 * tp][1] = hreg.y;
+                cin1[2 * tp + 1][0] = hreg.z; cin1[2 * tp + 1][1] = hreg.w;
+            }
+        };
+        if constexpr (!ST2) { if (pred) hand_in(0); }
 
         auto band = [&](auto PARc, int i) {
             constexpr int PAR = decltype(PARc)::value;
             float* const t1 = tile1[PAR];
             float* const t1n = tile1[PAR ^ 1];
-            // ------------------------------------ W(i) --------------------------------------------------
-            if (pred && !have_pref) {
-                // the neighbour had not published record i when this item looked: wait for it now
-                if (tid == 0) spin_pred((unsigned)i + 1u);
-                wg_barrier();
-                seen = s_seen;
-                if constexpr (ST2) fetch_rec(i);
-            }
-            if constexpr (!ST2) {
-                // a/b rows [10 (i-1) - 9, 10 (i-1) + 1) of X(i-1) -> tile 2 column jt; rows / columns outside the image:
-                // -0; the 19 halo columns of a strip with a left neighbour come from its record instead
-                const int il = opaque(lane) & 15;
-                const bool wr = comb_rho() < HW && !(pred && il == 0);
-                if (i >= 1 && wr) {
-                    const int ya0 = BH * (i - 1) - R;
-                    const bool redge = ya0 < 0 || ya0 + BH > h;
-                    const int xo = base2 + jt;
-                    const bool cok = xo >= 0 && xo < w;
-#pragma unroll
-                    for (int t = 0; t < BH; ++t) {
-                        f2 v = abreg[t];
-                        if (redge || xedge) {
-                            const int ya = ya0 + t;
-                            if (!(ya >= 0 && ya < h && cok)) v = NZ2;
-                        }
-                        tile_wr(tile2 + t * RS + jt, v);
-                    }
-                }
-            } else { if (pred) {
-                const int hq = hu_idx();
-                if (hq >= 0 && hq < NHU) {
-                    if (i >= 1) {
-                        const int t = hq / 10, j = (hq - 10 * t) * 2;
-                        float* dst = tile2 + t * RS + j;
-                        dst[0] = hreg.x;
-                        dst[P1] = hreg.y;
-                        if (j + 1 < HW) { dst[1] = hreg.z; dst[P1 + 1] = hreg.w; }
-                    }
-                } else if (hq >= NHU && hq < REC_U) {
-                    const int tp = hq - NHU;
-                    cin1[2 * tp][0] = hreg.x; cin1[2 * tp][1] = hreg.y;
-                    cin1[2 * tp + 1][0] = hreg.z; cin1[2 * tp + 1][1] = hreg.w;
-                }
-            } }
-            have_pref = false;
-            issue_cost(i + 1);                 // lands under the row scans
             wg_barrier();
 #ifdef SMX_V5_DUMP
             if (item == SMX_V5_DUMP && i == SMX_V5_DUMP_IT && SMX_V5_DUMP_PH == 0) {
@@ -508,9 +556,10 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
             }
 #endif
             // ------------------------------------ R(i) --------------------------------------------------
+            V5_STAMP(0);
             if (wave == 0) {
                 __builtin_amdgcn_s_setprio(3);
-                rowscans(i, t1);
+                if (!(WHATIF & 1)) rowscans(i, t1);
                 __builtin_amdgcn_s_setprio(0);
             } else {
                 if (wave == NWAVE - 1 && lane == 63) {
@@ -520,46 +569,33 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
                     if (i == NI - 1)
                         s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                eval_cost(i + 1, t1n);
+                // stage-1 inputs of band i+1: loaded and evaluated here, in the shadow of the row scans (no register
+                // carries them through another phase)
+                if (!(WHATIF & 2)) {
+                    const Raw rw = issue_cost(i + 1);
+                    eval_cost(i + 1, t1n, rw);
+                }
                 // every storing wave drains its global accesses before the barrier behind which one lane publishes
                 // the record stored in X(i-1)
                 if constexpr (ST2) drain_vmem();
             }
+            V5_STAMP(1);
             wg_barrier();
+            V5_STAMP(2);
 #ifdef SMX_V5_DUMP
             if (item == SMX_V5_DUMP && i == SMX_V5_DUMP_IT && SMX_V5_DUMP_PH == 1) {
                 for (int e = tid; e < TILE_F; e += NT) { g_dump[e] = t1[e]; g_dump[TILE_F + e] = tile2[e]; }
                 wg_barrier();
             }
 #endif
-            // ------------------------------------ X(i) --------------------------------------------------
+            // ------------------------------------ X1(i): stage 2 takes its rows out of tile 2 ----------------
             if (succ && tid == NT - 1 && i >= 1) flag_store(myflag, (unsigned)i);
             seen = s_seen;
-            if constexpr (!ST2) {
-                // an interior band: every window of its a/b rows is unclipped in y, and so are the rows GPF further down
-                const bool border = BH * i - R < R + 1 || BH * i - R + BH - 1 + GPF > h - 1 - R;
-                // (idle comb lanes -- the 20th DPP row -- run along on tile column 0: no branch around the loads)
-                f2 rv = tile_rd(t1 + jt);
-                __builtin_amdgcn_sched_barrier(0);
-#define V5_R1(TT, B) row1(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, i, t1, rv);
-                if (border) { V5_R1(0, true) V5_R1(1, true) V5_R1(2, true) V5_R1(3, true) V5_R1(4, true) V5_R1(5, true) V5_R1(6, true) V5_R1(7, true) V5_R1(8, true) V5_R1(9, true) }
-                else { V5_R1(0, false) V5_R1(1, false) V5_R1(2, false) V5_R1(3, false) V5_R1(4, false) V5_R1(5, false) V5_R1(6, false) V5_R1(7, false) V5_R1(8, false) V5_R1(9, false) }
-#undef V5_R1
-            } else {
-                // the left neighbour's record i+1 is needed first thing in the next iteration: its load goes out now
-                // (unconditionally: a load under a condition is waited for where the branches merge); what it
-                // returns counts only if the record had been published
-                fetch_rec(min(i + 1, NI - 1));
-                if (i >= 1) {
-                    const int yq0 = BH * (i - 1) - 2 * R;
-                    const bool border = yq0 < R + 1 || yq0 + BH - 1 + GPF > h - 1 - R;
-                    f2 rv = tile_rd(tile2 + jt);
-                    __builtin_amdgcn_sched_barrier(0);
-#define V5_R2(TT, B) row2(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, i, rv);
-                    if (border) { V5_R2(0, true) V5_R2(1, true) V5_R2(2, true) V5_R2(3, true) V5_R2(4, true) V5_R2(5, true) V5_R2(6, true) V5_R2(7, true) V5_R2(8, true) V5_R2(9, true) }
-                    else { V5_R2(0, false) V5_R2(1, false) V5_R2(2, false) V5_R2(3, false) V5_R2(4, false) V5_R2(5, false) V5_R2(6, false) V5_R2(7, false) V5_R2(8, false) V5_R2(9, false) }
-#undef V5_R2
-                }
+            f2 r2[ST2 ? BH : 1];
+            f2 rv = NZ2;
+            if constexpr (ST2) {
+#pragma unroll
+                for (int t = 0; t < BH; ++t) r2[t] = tile_rd(tile2 + t * RS + jt);
                 const int hq = hu_idx();
                 if (succ && hq >= 0 && hq < REC_U) {
                     // record i: stage-2 row prefix of the strip's last 19 columns (a/b band i-1), stage-1 row carries
@@ -574,15 +610,58 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
                     }
                     st16_sc1(r_hand, (unsigned)(o_out + i * REC_U * 16) + (unsigned)hq * 16u, hov);
                 }
+            } else {
+                // the left neighbour's record i+1 is needed at the end of this iteration: its load goes out now
+                // (unconditionally: a load under a condition is waited for where the branches merge); what it
+                // returns counts only if the record had been published
+                fetch_rec(min(i + 1, NI - 1));
+                rv = tile_rd(t1 + jt);
+            }
+            V5_STAMP(3);
+            wg_barrier();          // tile 2 is free: the a_k, b_k of this band go straight into it
+            V5_STAMP(4);
+            // ------------------------------------ X2(i): the comb rows ---------------------------------------
+            if constexpr (!ST2) {
+                // an interior band: every window of its a/b rows is unclipped in y, and so are the rows GPF further down
+                const bool border = BH * i - R < R + 1 || BH * i - R + BH - 1 + GPF > h - 1 - R;
+                // (idle comb lanes -- the 20th DPP row -- run along on tile column 0: no branch around the loads)
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(WHATIF & 4)) {
+#define V5_R1(TT, B) row1(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, i, t1, rv);
+                if (border) { V5_R1(0, true) V5_R1(1, true) V5_R1(2, true) V5_R1(3, true) V5_R1(4, true) V5_R1(5, true) V5_R1(6, true) V5_R1(7, true) V5_R1(8, true) V5_R1(9, true) }
+                else { V5_R1(0, false) V5_R1(1, false) V5_R1(2, false) V5_R1(3, false) V5_R1(4, false) V5_R1(5, false) V5_R1(6, false) V5_R1(7, false) V5_R1(8, false) V5_R1(9, false) }
+                }
+#undef V5_R1
+            } else {
+                if (i >= 1) {
+                    const int yq0 = BH * (i - 1) - 2 * R;
+                    const bool border = yq0 < R + 1 || yq0 + BH - 1 + GPF > h - 1 - R;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(WHATIF & 8)) {
+#define V5_R2(TT, B) row2(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, i, r2);
+                    if (border) { V5_R2(0, true) V5_R2(1, true) V5_R2(2, true) V5_R2(3, true) V5_R2(4, true) V5_R2(5, true) V5_R2(6, true) V5_R2(7, true) V5_R2(8, true) V5_R2(9, true) }
+                    else { V5_R2(0, false) V5_R2(1, false) V5_R2(2, false) V5_R2(3, false) V5_R2(4, false) V5_R2(5, false) V5_R2(6, false) V5_R2(7, false) V5_R2(8, false) V5_R2(9, false) }
+                    }
+#undef V5_R2
+                }
             }
             have_pref = pred && (seen == FLAG_DONE || seen >= (unsigned)i + 2u);
-            wg_barrier();
+            // ---- hand-in of record i+1 (needed by R(i+1)): prefetched at the top of X1 if it had been published
+            if (pred && !have_pref && i + 1 < NI) {
+                // the neighbour had not published it when this item looked: wait for it now
+                if (tid == 0) spin_pred((unsigned)i + 2u);
+                wg_barrier();
+                seen = s_seen;
+                if constexpr (!ST2) fetch_rec(min(i + 1, NI - 1));
+            }
+            if constexpr (!ST2) { if (pred && i + 1 < NI) hand_in(i + 1); }
+            V5_STAMP(5);
 #ifdef SMX_V5_DUMP
             if (item == SMX_V5_DUMP && i == SMX_V5_DUMP_IT && SMX_V5_DUMP_PH == 2) {
+                wg_barrier();
                 for (int e = tid; e < TILE_F; e += NT) { g_dump[e] = t1[e]; g_dump[TILE_F + e] = tile2[e]; }
 #pragma unroll
                 for (int s = 0; s < RD; ++s) { g_dump[2 * TILE_F + tid * 48 + 2 * s] = ring[s].x; g_dump[2 * TILE_F + tid * 48 + 2 * s + 1] = ring[s].y; }
-                wg_barrier();
             }
 #endif
         };
@@ -603,7 +682,94 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
 }
 #undef V5_BOX
 
+// ---------------------------------------------------------------------------------------------------------------
+// comb-ordered guidance planes: grid (K * h, nviews), block CLP
+// ---------------------------------------------------------------------------------------------------------------
+struct PermArgs {
+    const f2* G[2];
+    const fg_t* FG[2];
+    f2* g1p[2];
+    unsigned* i2p[2];
+};
+__global__ __launch_bounds__(CLP) void k_v5_perm(PermArgs pa, int w, int h) {
+    const int cl = threadIdx.x, rho = cl >> 4, il = cl & 15;
+    const int k = blockIdx.x / h, y = blockIdx.x - k * h, v = blockIdx.y;
+    const int x1 = OWS * k - R - 1 + HW * il + rho;     // a/b column of stage-1 comb lane cl
+    const int xq = x1 - R;                              // q column of stage-2 comb lane cl
+    f2 g = {0.0f, 0.0f};
+    unsigned iv = 0;
+    if (rho < HW) {
+        if (x1 >= 0 && x1 < w) g = pa.G[v][(size_t)y * w + x1];
+        if (xq >= 0 && xq < w) iv = __builtin_bit_cast(unsigned, pa.FG[v][(size_t)y * (w + 2 * PADX) + PADX + xq]);
+    }
+    const size_t o = ((size_t)k * h + y) * CLP + cl;
+    pa.g1p[v][o] = g;
+    pa.i2p[v][o] = iv;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// WTA over the chunk's comb-ordered q planes [slice][K][h][OWS] (dispSelectOnGPU guidedFilter.cu:403-411 in
+// packed-key form): one lane per element, coalesced nt loads, 8 in flight; the keys stay [h][w] -- the lane finds
+// its pixel once per call.  grid (ceil(K h OWS / 256), nviews)
+// ---------------------------------------------------------------------------------------------------------------
+struct Wta5Args {
+    const float* q[2];
+    int64_t* keys[2];
+};
+__global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K, int count, int slice0) {
+    const size_t np = (size_t)K * h * OWS;
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= np) return;
+    const int row = (int)(e / OWS), p = (int)(e - (size_t)row * OWS);   // row = k h + y
+    const int k = row / h, y = row - k * h;
+    const int rho = p / 15, i1 = p - 15 * rho;
+    const int x = OWS * k + HW * i1 + rho;
+    if (x >= w) return;
+    const float* __restrict__ q = wa.q[blockIdx.y] + e;
+    int64_t* kp = wa.keys[blockIdx.y] + (size_t)y * w + x;
+    int64_t key = *kp;
+    int z = 0;
+    constexpr int U = 8;
+    for (; z + U <= count; z += U) {
+        float v[U];
+#pragma unroll
+        for (int t = 0; t < U; ++t) v[t] = __builtin_nontemporal_load(&q[(size_t)(z + t) * np]);
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            const int64_t kk = pack_key(v[t], (uint32_t)(slice0 + z + t));
+            key = kk < key ? kk : key;
+        }
+    }
+    for (; z < count; ++z) {
+        const int64_t kk = pack_key(__builtin_nontemporal_load(&q[(size_t)z * np]), (uint32_t)(slice0 + z));
+        key = kk < key ? kk : key;
+    }
+    *kp = key;
+}
+
 }  // namespace v5
+
+int v5_perm_launch(int nviews, const aggdev::f2* const* G, const aggdev::fg_t* const* FG, aggdev::f2* const* g1p,
+                   unsigned* const* i2p, int w, int h, hipStream_t st) {
+    v5::PermArgs pa;
+    memset(&pa, 0, sizeof(pa));
+    for (int v = 0; v < nviews; ++v) { pa.G[v] = G[v]; pa.FG[v] = FG[v]; pa.g1p[v] = g1p[v]; pa.i2p[v] = i2p[v]; }
+    hipLaunchKernelGGL(v5::k_v5_perm, dim3((unsigned)(v5::strips(w) * h), (unsigned)nviews), dim3(v5::CLP), 0, st, pa, w, h);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+int v5_wta_launch(int nviews, const float* const* q, int64_t* const* keys, int w, int h, int count, int slice0,
+                  hipStream_t st) {
+    v5::Wta5Args wa;
+    for (int v = 0; v < 2; ++v) { wa.q[v] = q[v < nviews ? v : 0]; wa.keys[v] = keys[v < nviews ? v : 0]; }
+    const int K = v5::strips(w);
+    const size_t np = (size_t)K * h * v5::OWS;
+    hipLaunchKernelGGL(v5::k_v5_wta, dim3((unsigned)((np + 255) / 256), (unsigned)nviews), dim3(256), 0, st, wa, w, h, K,
+                       count, slice0);
+    SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
 
 bool v5_supported(const smx_params* p) {
     if (p->radius != v5::R) return false;
@@ -634,6 +800,13 @@ int v5_launch(const v5::Args& a, hipStream_t st) {
     return SMX_OK;
 }
 
+#ifdef SMX_V5_STAMPS
+extern "C" __attribute__((visibility("default"))) int smx_debug_read_stamps5(unsigned long long* out, int n) {
+    const int m = 10 * v5::STAMP_SLOTS;
+    SMX_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(v5::g_stamps), sizeof(unsigned long long) * (n < m ? n : m)));
+    return m;
+}
+#endif
 #ifdef SMX_V5_DUMP
 extern "C" __attribute__((visibility("default"))) int smx_debug_read_dump5(float* out, int n) {
     const int m = 2 * v5::TILE_F + v5::NT * 48;

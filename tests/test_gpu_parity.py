@@ -726,6 +726,40 @@ def test_pair_4k_shape_properties():
 # N > 1 end to end on one GPU: two processes, each aggregating its disparity shard with the HIP
 # kernels on cuda:0, merged by the product's all-reduce (gloo here; RCCL on a multi-GPU node).
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,ranges,sif", [
+    ("motorcycle", [(0, 3), (137, 140), (100, 103), (277, 280)], 2),
+    ("4k", [(0, 2), (255, 258), (510, 512)], 2),
+])
+def test_full_geometry_slices_equal_the_oracle(orc, shape, ranges, sif):
+    """BASELINE configs 3 and 5 pinned to the ORACLE at full geometry (2964x2000 D=280, 3840x2160 D=512) on sampled
+    slice ranges -- first, last, inside, and (slices_in_flight = 2) one that straddles a workspace chunk: aggregated
+    planes and the packed keys of the range, bit for bit, through both q layouts of the comb walker (the caller's
+    [z][y][x] volume / the comb-ordered scratch + its WTA pass).  The reference overflows its 32-bit sizes at these
+    shapes (guidedFilter.cu:6-7,26, costVolume.cu:6,178); a 32-bit offset, band / strip count or chunking defect
+    here would show."""
+    import torch
+    from stereo_matching_cuda_amd.device import PairPipeline
+    w, h, D = synth.SHAPES[shape]
+    Il, Ir = synth.gen_pair(w, h, D, synth.SEEDS[shape])
+    dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
+    dminl, dminr = -(D - 1), 0
+    for s0, s1 in ranges:
+        aggl, keysl = orc.guided_filter_slices(Il, Ir, dminl, s0, s1)
+        aggr, keysr = orc.guided_filter_slices(Ir, Il, dminr, s0, s1)
+        for want_agg in (True, False):
+            pipe = PairPipeline(w, h, D, s_begin=s0, s_end=s1, slices_in_flight=sif, want_agg=want_agg)
+            pipe.aggregate(dl, dr)
+            pipe.check_status()
+            keys = pipe.keys.cpu().numpy()
+            _eq(keys[0], keysl, f"{shape} [{s0},{s1}) agg={want_agg} keys l")
+            _eq(keys[1], keysr, f"{shape} [{s0},{s1}) agg={want_agg} keys r")
+            if want_agg:
+                _eq(pipe.agg[0].cpu().numpy(), aggl, f"{shape} [{s0},{s1}) agg l")
+                _eq(pipe.agg[1].cpu().numpy(), aggr, f"{shape} [{s0},{s1}) agg r")
+            del pipe
+        torch.cuda.empty_cache()
+
+
 def _rank_worker(rank, world, port, Il, Ir, D, out_dir):
     import os
     import torch

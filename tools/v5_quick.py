@@ -12,10 +12,10 @@ from stereo_matching_cuda_amd.device import PairPipeline
 KEYS = ("meanl", "meanr", "aggl", "aggr", "dmapl", "dmapr", "bestl", "bestr", "occlusion", "filled")
 
 
-def run(w, h, D, seed, path=5):
+def run(w, h, D, seed, path=5, want_agg=True):
     Il, Ir = synth.gen_pair(w, h, D, seed)
     ref = oracle.stereo_pair(Il, Ir, D, want_agg=True)
-    pipe = PairPipeline(w, h, D, want_agg=True)
+    pipe = PairPipeline(w, h, D, want_agg=want_agg)
     dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
     smx.check(smx.lib().smx_set_agg_path(path))
     try:
@@ -25,6 +25,8 @@ def run(w, h, D, seed, path=5):
         smx.lib().smx_set_agg_path(0)
     ok = True
     for k in KEYS:
+        if k not in got:
+            continue
         a, b = np.asarray(got[k]), np.asarray(ref[k]).reshape(np.asarray(got[k]).shape)
         bad = (a.view(np.uint32) != b.view(np.uint32)) if a.dtype == np.float32 else (a != b)
         nb = int(bad.sum())
@@ -40,7 +42,7 @@ def run(w, h, D, seed, path=5):
             if k.startswith("agg"):
                 cols = np.unique(idx[:, -1]); rows = np.unique(idx[:, -2]); sl = np.unique(idx[:, 0])
                 print("    slices", sl[:8], "rows", rows[:12], "cols", cols[:24], "ncols", cols.size, "nrows", rows.size)
-    print(f"{w}x{h} D={D} path {path}: {'OK' if ok else 'MISMATCH'}", flush=True)
+    print(f"{w}x{h} D={D} path {path} agg={want_agg}: {'OK' if ok else 'MISMATCH'}", flush=True)
     return ok
 
 
@@ -69,8 +71,11 @@ def timeit(path, w, h, D, n=20):
 if __name__ == "__main__":
     shapes = [(70, 40, 3, 1), (285, 30, 2, 2), (286, 21, 2, 6), (384, 288, 16, 4), (600, 95, 4, 3), (1242, 64, 3, 5)]
     allok = True
+    if "--time-only" in sys.argv:
+        shapes = []
     for s in shapes:
         allok &= run(*s)
+        allok &= run(*s, want_agg=False)      # the comb-ordered q scratch + its WTA pass
         if not allok and "--all" not in sys.argv:
             break
     if allok and "--kitti" in sys.argv:
