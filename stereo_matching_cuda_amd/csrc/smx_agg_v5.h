@@ -21,7 +21,7 @@ struct Args {
     // comb-ordered copies (k_v5_perm): what a comb lane cl = 16 rho + il of strip k needs in row y sits at
     // [k][y][cl], so that a wave's guidance load is one contiguous run instead of 16 clusters of 4 columns
     unsigned o_g1p[2];    // float2 [K][h][CLP]: (mean_I, 1/(var_I + eps)) at the a/b column 285 k - 10 + 19 il + rho
-    unsigned o_i2p[2];    // u32    [K][h][CLP]: raw (value, gradient) halves at the q column 285 k - 19 + 19 il + rho
+    unsigned o_i2p[2];    // u32    [K][(h+1)/2][CLP]: image values (fp16) of rows 2 m, 2 m + 1 at the q column 285 k - 19 + 19 il + rho
     // out, per view: qperm != 0: comb-ordered scratch [slice][K][h][OWS], column 285 k + 19 (il-1) + rho at
     // [15 rho + il - 1] (a wave stores 240 contiguous bytes; read back by k_v5_wta); else the caller's [slice][h][w]
     float* q[2];

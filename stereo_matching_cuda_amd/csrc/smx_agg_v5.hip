@@ -88,7 +88,8 @@ __device__ unsigned long long g_stamps[10 * STAMP_SLOTS];
 #endif
 // Diagnostic build only (-DSMX_V5_WHATIF=<bits>): leaves parts of the work out (WRONG results) to see what the
 // kernel time is sensitive to.  1: no row scans; 2: no cost evaluation; 4: no stage-1 comb rows; 8: no stage-2 comb
-// rows; 16: no q stores; 32: no guidance loads; 64: no hand-off (every strip like strip 0); 128: no input loads
+// rows; 16: no q stores; 32: no guidance loads; 64: no hand-off (every strip like strip 0); 128: no input loads;
+// 256: row scans without their LDS writes; 512: row scans without the adds; 1024: row scans at normal priority
 #ifndef SMX_V5_WHATIF
 #define SMX_V5_WHATIF 0
 #endif
@@ -206,7 +207,8 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
         const rsrc_t r_fix = mk_rsrc(A.fix, A.fix_bytes);
         const int o_fg1 = (int)A.o_fg[view], o_fg2 = (int)A.o_fg[view ^ 1];
         // this strip's rows of the comb-ordered guidance planes
-        const int o_g1p = (int)(A.o_g1p[view] + (unsigned)k * (unsigned)h * (CLP * 8u)), o_i2p = (int)(A.o_i2p[view] + (unsigned)k * (unsigned)h * (CLP * 4u));
+        const int o_g1p = (int)(A.o_g1p[view] + (unsigned)k * (unsigned)h * (CLP * 8u)),
+                  o_i2p = (int)(A.o_i2p[view] + (unsigned)k * (unsigned)((h + 1) / 2) * (CLP * 4u));
         const unsigned recb = (unsigned)NI * REC_U * 16u;        // bytes per (parity, slice-view)
         const rsrc_t r_hand = mk_rsrc(A.hand, (size_t)2 * nsv * recb);
         const int o_in = (int)((((unsigned)(k - 1) & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
@@ -252,9 +254,10 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
         ring[ST2 ? 10 : RD - 1] = NZ2;   // the slot in front of the first row (stage 1: row 0; stage 2: row -9)
         // (arrays of the other role shrink to one element: the two roles are separate instantiations, so that no
         // register carries state of the other role around the band loop)
-        constexpr int GPF = ST2 ? 4 : 2;     // guidance rows in flight per lane
-        f2 gq[ST2 ? 1 : GPF];                // stage 1: (mean_I, 1/(var+eps))
-        unsigned gI[ST2 ? GPF : 1];          // stage 2: raw (value, gradient) halves of the guidance image
+        // guidance of the band's output rows: loaded at the end of R (a barrier and the X1 phase ahead of the rows that
+        // use it), consumed row by row in X2
+        f2 gq[ST2 ? 1 : BH];                 // stage 1: (mean_I, 1/(var+eps)) of the a/b rows
+        unsigned gI[ST2 ? BH / 2 : 1];       // stage 2: guidance image values of two q rows each (fp16 pairs)
         f4 hreg = {0, 0, 0, 0};              // (stage-1 role, threads 0 .. REC_U-1) this thread's unit of the left neighbour's next record
         bool have_pref = false;
         unsigned seen = 0;
@@ -332,16 +335,23 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
                 *(f2*)(p + P1) = py;
             }
         };
-        // guidance of output row yrow -> slot (rows clamped into the image: every load is issued)
-        // (the rows an interior band asks for all exist: no clamp)
-        auto issue_guid = [&](int slot, int yrow, bool clamp) {
+        // guidance of the output rows of iteration ib (rows clamped into the image: every load is issued)
+        auto issue_guid = [&](int ib) {
             if (WHATIF & 32) return;
-            const int y = clamp ? min(max(yrow, 0), h - 1) : yrow;
             if constexpr (!ST2) {
-                const u2 g = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)vg, o_g1p + y * (CLP * 8), 0);
-                gq[slot] = __builtin_bit_cast(f2, g);
+#pragma unroll
+                for (int t = 0; t < BH; ++t) {
+                    const int y = min(max(BH * ib - R + t, 0), h - 1);
+                    const u2 g = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)vg, o_g1p + y * (CLP * 8), 0);
+                    gq[t] = __builtin_bit_cast(f2, g);
+                }
             } else {
-                gI[slot] = ldu(r_fix, vg, o_i2p + y * (CLP * 4));
+                // q rows 10 (ib-1) - 18 + 2 m, + 1: the first one is even, so a pair is one element of the row-pair plane
+#pragma unroll
+                for (int m = 0; m < BH / 2; ++m) {
+                    const int yp = min(max((BH * (ib - 1) - 2 * R) / 2 + m, 0), (h - 1) / 2);
+                    gI[m] = ldu(r_fix, vg, o_i2p + yp * (CLP * 4));
+                }
             }
         };
 
@@ -380,44 +390,37 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
             const bool keep = sc_st == 1 && pred;
             float acc = (sc_st == 0 && pred) ? cin1[sc_row][sc_comp] : -0.0f;
             f4* const r4 = (f4*)row;
-            constexpr int NG = SW / 4, PF = 4;
+            constexpr int NG = SW / 4;
+#ifndef SMX_V5_SCAN_PF
+#define SMX_V5_SCAN_PF 8
+#endif
+            constexpr int PF = SMX_V5_SCAN_PF;          // groups of reads in flight ahead of the dependent adds
             f4 v[PF];
 #pragma unroll
             for (int g = 0; g < PF; ++g) v[g] = r4[g];
-            // groups 0 .. 4 (columns 0 .. 19): the variant that can leave the halo columns 0 .. 18 untouched
+            f4 xo[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+            // fully unrolled: static registers for the reads in flight; the sums of two consecutive groups live in
+            // different registers, so that the adds of a group do not wait until the 16-byte store of the previous one has
+            // read its four source registers.  Groups 0 .. 4 (columns 0 .. 19) can leave the halo columns 0 .. 18 untouched.
 #pragma unroll
-            for (int g = 0; g < 5; ++g) {
+            for (int g = 0; g < NG; ++g) {
                 const f4 in = v[g % PF];
-                v[g % PF] = r4[g + PF];
-                f4 x;
+                if (g + PF < NG) v[g % PF] = r4[g + PF];
+                f4& x = xo[g & 1];
+                if ((WHATIF & 512) && g >= 5) { x = in; } else {
                 acc = in.x + acc; x.x = acc;
                 acc = in.y + acc; x.y = acc;
                 acc = in.z + acc; x.z = acc;
                 if (g == 4 && keep) acc = in.z;            // column 18 = the halo's last: the carry
                 acc = in.w + acc; x.w = acc;
-                if (keep) { x.x = in.x; x.y = in.y; x.z = in.z; if (g < 4) x.w = in.w; }
-                r4[g] = x;
-            }
-            // groups 5 .. 75: PF groups of reads ahead of the dependent adds (past the end they re-read the last group)
-            f4 xo[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-            for (int g0 = 5; g0 < NG; g0 += PF) {
-#pragma unroll
-                for (int u = 0; u < PF; ++u) {
-                    const int g = g0 + u;
-                    if (g < NG) {
-                        const f4 in = v[(5 + u) % PF];
-                        v[(5 + u) % PF] = r4[min(g + PF, NG - 1)];
-                        // the sums of two consecutive groups live in different registers: the adds of a group then do not
-                        // wait until the 16-byte store of the previous one has read its four source registers
-                        f4& x = xo[u & 1];
-                        acc = in.x + acc; x.x = acc;
-                        acc = in.y + acc; x.y = acc;
-                        acc = in.z + acc; x.z = acc;
-                        acc = in.w + acc; x.w = acc;
-                        r4[g] = x;
-                        asm volatile("" :: "v"(xo[(u & 1) ^ 1]));
-                    }
                 }
+                if (g < 5 && keep) { x.x = in.x; x.y = in.y; x.z = in.z; if (g < 4) x.w = in.w; }
+#ifdef SMX_V5_SCAN_W64
+                if (!((WHATIF & 256) && g >= 5)) { ((f2*)row)[2 * g] = (f2){x.x, x.y}; ((f2*)row)[2 * g + 1] = (f2){x.z, x.w}; }
+#else
+                if (!((WHATIF & 256) && g >= 5)) r4[g] = x; else asm volatile("" :: "v"(x));
+#endif
+                asm volatile("" :: "v"(xo[(g & 1) ^ 1]));
             }
         };
 
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
             f2 u;
             V5_BOX(u, SL, SL01);
             const f2 m = div_ca(u, area_of(BH * i - R + T, BORDERc));   // (mean_p, mean_Ip); no window sum of p, I p can be tiny (smx_agg_v5.h)
-            const f2 g = gq[N % GPF];
+            const f2 g = gq[T];
             // compute_ak_and_bk guidedFilter.cu:345-354
             const float mm = g.x * m.x;
             const float ak = 1.0f * (m.y - mm) * g.y;
@@ -468,8 +471,6 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
                 if (!(col_ok && ya >= 0 && ya < h)) ab = NZ2;
             }
             tile_wr(tile2 + T * RS + jw, ab);
-            // the guidance of the row GPF rows further down (next band: its first rows)
-            issue_guid(N % GPF, BH * i - R + T + GPF, BORDER);
             rv = rvn;
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -493,25 +494,17 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
                 m.x = 1.0f * u.x / ca.y;
                 m.y = 1.0f * u.y / ca.y;
             }
-            const float Iv = (float)__builtin_bit_cast(fg_t, gI[N % GPF]).x;
+            const fg_t ip = __builtin_bit_cast(fg_t, gI[T / 2]);
+            const float Iv = (float)(T & 1 ? ip.y : ip.x);
             const float tq = m.x * Iv;                     // compute_q guidedFilter.cu:363-369
             const float qv = tq + m.y;
             if (!(WHATIF & 16) && (!BORDER || (yq >= 0 && yq < h)))
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qv), r_q, (int)vo, q_row0 + yq * q_pitch, AUX_NT);
-            issue_guid(N % GPF, yq + GPF, BORDER);
             __builtin_amdgcn_sched_barrier(0);
         };
 
         // ===================================== the band loop ==============================================
         // prologue: stage-1 inputs of band 0 -> tile 1[0]; guidance of the first rows; the left neighbour's record 0
-        // (stage 2 starts at i = 1 with comb rows N = 10 .. 13: slots 2, 3, 0, 1)
-        if constexpr (ST2) {
-#pragma unroll
-            for (int s = 0; s < GPF; ++s) issue_guid((BH + s) % GPF, -2 * R + s, true);
-        } else {
-#pragma unroll
-            for (int s = 0; s < GPF; ++s) issue_guid(s, -R + s, true);
-        }
         if (pred) {
             if (tid == 0) spin_pred(1u);
             wg_barrier();
@@ -558,7 +551,7 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
             // ------------------------------------ R(i) --------------------------------------------------
             V5_STAMP(0);
             if (wave == 0) {
-                __builtin_amdgcn_s_setprio(3);
+                if (!(WHATIF & 1024)) __builtin_amdgcn_s_setprio(3);
                 if (!(WHATIF & 1)) rowscans(i, t1);
                 __builtin_amdgcn_s_setprio(0);
             } else {
@@ -579,6 +572,7 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
                 // the record stored in X(i-1)
                 if constexpr (ST2) drain_vmem();
             }
+            issue_guid(i);
             V5_STAMP(1);
             wg_barrier();
             V5_STAMP(2);
@@ -622,8 +616,8 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
             V5_STAMP(4);
             // ------------------------------------ X2(i): the comb rows ---------------------------------------
             if constexpr (!ST2) {
-                // an interior band: every window of its a/b rows is unclipped in y, and so are the rows GPF further down
-                const bool border = BH * i - R < R + 1 || BH * i - R + BH - 1 + GPF > h - 1 - R;
+                // an interior band: every window of its a/b rows is unclipped in y
+                const bool border = BH * i - R < R + 1 || BH * i - R + BH - 1 > h - 1 - R;
                 // (idle comb lanes -- the 20th DPP row -- run along on tile column 0: no branch around the loads)
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(WHATIF & 4)) {
@@ -635,7 +629,7 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
             } else {
                 if (i >= 1) {
                     const int yq0 = BH * (i - 1) - 2 * R;
-                    const bool border = yq0 < R + 1 || yq0 + BH - 1 + GPF > h - 1 - R;
+                    const bool border = yq0 < R + 1 || yq0 + BH - 1 > h - 1 - R;
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(WHATIF & 8)) {
 #define V5_R2(TT, B) row2(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, i, r2);
@@ -697,14 +691,17 @@ __global__ __launch_bounds__(CLP) void k_v5_perm(PermArgs pa, int w, int h) {
     const int x1 = OWS * k - R - 1 + HW * il + rho;     // a/b column of stage-1 comb lane cl
     const int xq = x1 - R;                              // q column of stage-2 comb lane cl
     f2 g = {0.0f, 0.0f};
-    unsigned iv = 0;
-    if (rho < HW) {
-        if (x1 >= 0 && x1 < w) g = pa.G[v][(size_t)y * w + x1];
-        if (xq >= 0 && xq < w) iv = __builtin_bit_cast(unsigned, pa.FG[v][(size_t)y * (w + 2 * PADX) + PADX + xq]);
+    if (rho < HW && x1 >= 0 && x1 < w) g = pa.G[v][(size_t)y * w + x1];
+    pa.g1p[v][((size_t)k * h + y) * CLP + cl] = g;
+    if ((y & 1) == 0) {
+        // image values of rows y, y + 1 as one fp16 pair
+        fg_t pr = {(_Float16)0.0f, (_Float16)0.0f};
+        if (rho < HW && xq >= 0 && xq < w) {
+            pr.x = pa.FG[v][(size_t)y * (w + 2 * PADX) + PADX + xq].x;
+            if (y + 1 < h) pr.y = pa.FG[v][(size_t)(y + 1) * (w + 2 * PADX) + PADX + xq].x;
+        }
+        pa.i2p[v][((size_t)k * ((h + 1) / 2) + y / 2) * CLP + cl] = __builtin_bit_cast(unsigned, pr);
     }
-    const size_t o = ((size_t)k * h + y) * CLP + cl;
-    pa.g1p[v][o] = g;
-    pa.i2p[v][o] = iv;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -797,6 +794,18 @@ int v5_launch(const v5::Args& a, hipStream_t st) {
     const int grid = a.nitems < slots ? a.nitems : slots;
     hipLaunchKernelGGL((v5::k_v5_walk<0>), dim3((unsigned)grid), dim3(v5::NT), 0, st, a);
     SMX_HIP(hipGetLastError());
+    return SMX_OK;
+}
+
+// Residency of the walker as the runtime sees it (dev tool: tools/v5_quick.py --occupancy)
+extern "C" __attribute__((visibility("default"))) int smx_debug_v5_occupancy(int* blocks_per_cu, int* vgprs, int* lds_bytes) {
+    int nb = 0;
+    SMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)v5::k_v5_walk<0>, v5::NT, 0));
+    hipFuncAttributes fa;
+    SMX_HIP(hipFuncGetAttributes(&fa, (const void*)v5::k_v5_walk<0>));
+    if (blocks_per_cu) *blocks_per_cu = nb;
+    if (vgprs) *vgprs = fa.numRegs;
+    if (lds_bytes) *lds_bytes = (int)fa.sharedSizeBytes;
     return SMX_OK;
 }
 

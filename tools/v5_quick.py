@@ -68,7 +68,19 @@ def timeit(path, w, h, D, n=20):
     print(f"path {path} {w}x{h}x{D}: ms/pair median {ts[n // 2]:.3f} min {ts[0]:.3f} max {ts[-1]:.3f}", flush=True)
 
 
+def occupancy():
+    import ctypes as C
+    from stereo_matching_cuda_amd import _lib
+    L = C.CDLL(_lib.SO_PATH)
+    nb, vg, lds = C.c_int(), C.c_int(), C.c_int()
+    rc = L.smx_debug_v5_occupancy(C.byref(nb), C.byref(vg), C.byref(lds))
+    print(f"k_v5_walk: rc {rc} blocks per CU {nb.value} VGPRs {vg.value} LDS {lds.value} B", flush=True)
+
+
 if __name__ == "__main__":
+    if "--occupancy" in sys.argv:
+        torch.zeros(1).cuda()
+        occupancy()
     shapes = [(70, 40, 3, 1), (285, 30, 2, 2), (286, 21, 2, 6), (384, 288, 16, 4), (600, 95, 4, 3), (1242, 64, 3, 5)]
     allok = True
     if "--time-only" in sys.argv:
