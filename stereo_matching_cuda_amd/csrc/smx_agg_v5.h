@@ -6,11 +6,20 @@
 namespace smx {
 namespace v5 {
 
-constexpr int OWS = 285;                // output columns per strip (19 combs x 15 outputs)
+// Comb length: 16 = one comb per 16-lane DPP row, five comb waves per stage, 640-thread workgroups (only one of
+// which fits a CU: 3 + 3 + 2 + 2 waves per SIMD at 96 VGPRs); 12 = five combs per wave, four comb waves per stage,
+// 512-thread workgroups (two waves per SIMD each: two per CU at 128 VGPRs)
+#ifndef SMX_V5_L
+#define SMX_V5_L 12
+#endif
+constexpr int L = SMX_V5_L;             // lanes of a comb
+constexpr int CPW = 64 / L;             // combs per wave
+constexpr int NS1 = (19 + CPW - 1) / CPW;   // comb waves per stage
+constexpr int OWS = 19 * (L - 1);       // output columns per strip (19 combs x (L - 1) outputs)
 constexpr int BH = 10;                  // band height
 constexpr int REC_U = 105;              // 16-byte units per hand-off record
 constexpr int WG_PER_CU = 2;
-constexpr int CLP = 320;                // comb lanes per stage and strip (5 waves; 304 in use)
+constexpr int CLP = 64 * NS1;           // comb lane slots per stage and strip
 
 struct Args {
     // the fixed part of the workspace: both image planes [h][w + 2 PADX] of k_v4_prep and the guidance planes
@@ -20,10 +29,10 @@ struct Args {
     unsigned o_fg[2];     // byte offset of view v's image plane (the other view's is o_fg[v ^ 1])
     // comb-ordered copies (k_v5_perm): what a comb lane cl = 16 rho + il of strip k needs in row y sits at
     // [k][y][cl], so that a wave's guidance load is one contiguous run instead of 16 clusters of 4 columns
-    unsigned o_g1p[2];    // float2 [K][h][CLP]: (mean_I, 1/(var_I + eps)) at the a/b column 285 k - 10 + 19 il + rho
-    unsigned o_i2p[2];    // u32    [K][(h+1)/2][CLP]: image values (fp16) of rows 2 m, 2 m + 1 at the q column 285 k - 19 + 19 il + rho
-    // out, per view: qperm != 0: comb-ordered scratch [slice][K][h][OWS], column 285 k + 19 (il-1) + rho at
-    // [15 rho + il - 1] (a wave stores 240 contiguous bytes; read back by k_v5_wta); else the caller's [slice][h][w]
+    unsigned o_g1p[2];    // float2 [K][h][CLP]: (mean_I, 1/(var_I + eps)) at the a/b column OWS k - 10 + 19 il + rho
+    unsigned o_i2p[2];    // u32    [K][(h+1)/2][CLP]: image values (fp16) of rows 2 m, 2 m + 1 at the q column OWS k - 19 + 19 il + rho
+    // out, per view: qperm != 0: comb-ordered scratch [slice][K][h][OWS], column OWS k + 19 (il-1) + rho at
+    // [(L-1) rho + il - 1] (a wave stores one contiguous run; read back by k_v5_wta); else the caller's [slice][h][w]
     float* q[2];
     int qperm;
     size_t q_plane;       // floats per slice of q

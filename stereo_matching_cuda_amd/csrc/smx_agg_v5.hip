@@ -50,18 +50,17 @@ namespace v5 {
 using namespace aggdev;
 
 constexpr int R = 9, HW = 2 * R + 1;
-constexpr int L = 16;                   // lanes of a comb = one DPP row
-constexpr int SW = HW * L;              // 304 integral-image columns per strip (tile columns)
-static_assert(OWS == HW * (L - 1) && SW == OWS + HW, "strip geometry");
+constexpr int SW = HW * L;              // integral-image columns per strip = tile columns (304 / 228)
+static_assert(OWS == HW * (L - 1) && SW == OWS + HW && SW % 4 == 0 && CPW * L <= 64 && CPW * NS1 >= HW, "strip geometry");
 constexpr int RD = 20;                  // ring slots (>= 2R+2; a multiple of BH: static slots)
 static_assert(RD % BH == 0 && RD >= HW + 1, "ring");
-constexpr int NT = 640, NWAVE = NT / 64, NS1 = 5;
-static_assert(NS1 * 64 >= SW && 2 * NS1 == NWAVE, "five comb waves per stage");
+constexpr int NWAVE = 2 * NS1, NT = 64 * NWAVE;      // 640 / 512 threads
+constexpr int WPE = NWAVE == 8 ? 4 : 5;             // waves per SIMD the register budget is set for (128 / 96 VGPRs)
 // A tile row is component-planar: first components (p / a) at [0, 304), second ones (I p / b) at [P1, P1 + 304):
 // the row scan moves four columns of one component per LDS instruction, a comb lane reads its cell's pair with
 // one ds_read2st64_b32 (offset1 = P1 / 64).
-constexpr int P1 = 320;
-constexpr int RS = 644;                 // row stride in floats (4 mod 64: the scan lanes of different rows spread over the banks)
+constexpr int P1 = (SW + 63) / 64 * 64;                 // 320 / 256
+constexpr int RS = (P1 + SW + 16 + 63) / 64 * 64 + 4;   // row stride in floats, 4 mod 64: the scan lanes of different rows spread over the banks (644 / 516)
 constexpr int TILE_F = BH * RS;
 static_assert(P1 % 64 == 0 && P1 >= SW && RS >= P1 + SW && RS % 4 == 0, "tile row");
 
@@ -107,12 +106,18 @@ __device__ float g_dump[2 * TILE_F + NT * 48];
 // compiler's hazard recogniser does not look into inline assembly.
 __device__ __forceinline__ float sub_left(float own, float left) {      // own - left[lane-1]
     float d;
-    asm("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(left), "v"(own));
+    if (L == 16)
+        asm("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(left), "v"(own));
+    else
+        asm("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(left), "v"(own));
     return d;
 }
 __device__ __forceinline__ float add_left(float own, float left) {      // own + left[lane-1]
     float d;
-    asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(left), "v"(own));
+    if (L == 16)
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(left), "v"(own));
+    else
+        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(left), "v"(own));
     return d;
 }
 
@@ -146,7 +151,7 @@ __device__ __forceinline__ f2 tile_rd(const float* p) { return (f2){p[0], p[P1]}
 __device__ __forceinline__ void tile_wr(float* p, f2 v) { p[0] = v.x; p[P1] = v.y; }
 
 template <int DUMMY>
-__global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
+__global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     __shared__ __attribute__((aligned(16))) float tile1[2][TILE_F];
     __shared__ __attribute__((aligned(16))) float tile2[TILE_F];
     __shared__ float cin1[BH][2];                                   // stage-1 row carries of the current band
@@ -165,10 +170,15 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
     const bool st2w = wave >= NS1;
     // (per-lane values that only one phase of an iteration needs are re-derived from the thread index where they
     // are used -- a handful of integer instructions per band -- instead of living in VGPRs through the comb rows)
-    auto comb_rho = [&]() { return (64 * (wave - (st2w ? NS1 : 0)) + opaque(lane)) >> 4; };   // DPP row = residue; 19 idles
+    // comb of this lane = residue rho (>= 19: the lane idles), position il in the comb
+    auto comb_il = [&]() { return L == 16 ? (opaque(lane) & 15) : opaque(lane) % L; };
+    auto comb_rho = [&]() {
+        const int l = opaque(lane), c = L == 16 ? l >> 4 : l / L;
+        return c < CPW ? CPW * (wave - (st2w ? NS1 : 0)) + c : HW;
+    };
     auto comb_jt = [&]() {
-        const int rho = comb_rho(), il = opaque(lane) & 15;
-        return rho < HW ? HW * il + rho : 0;                        // (the 20th DPP row of a stage runs along on column 0)
+        const int rho = comb_rho(), il = comb_il();
+        return rho < HW ? HW * il + rho : 0;                        // (idle lanes run along on column 0)
     };
     constexpr int NQROW = SW / 4;                                   // 76 quads per tile row
     constexpr int NCT = NT - 64;                                    // 576 cost threads (waves 1..9)
@@ -229,22 +239,23 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
         unsigned vg;                                                // byte offset of this lane in a row of the comb-ordered guidance plane
         bool col_ok;
         {
-            const int il = lane & 15;
+            const int il = comb_il();
             const int xo = (ST2 ? base2 - R : base2) + jt;          // a/b column (stage 1) / q column (stage 2)
             col_ok = comb_rho() < HW && xo >= 0 && xo < w && (!ST2 || il >= 1);
             xw = col_ok ? min(w - 1, xo + R) - max(-1, xo - R - 1) : 1;
             rcp_i = rcp_s[HW * xw];
             {
-                const int cl = comb_rho() * 16 + il;
+                const int cl = 64 * (wave - (st2w ? NS1 : 0)) + lane;          // slot in a row of the comb-ordered planes
                 vg = (unsigned)cl * (ST2 ? 4u : 8u);
-                vo = !col_ok ? OOB : (A.qperm ? (unsigned)(15 * comb_rho() + il - 1) * 4u : (unsigned)xo * 4u);
+                vo = !col_ok ? OOB : (A.qperm ? (unsigned)((L - 1) * comb_rho() + il - 1) * 4u : (unsigned)xo * 4u);
             }
         }
         const f2 ca_i = {rcp_i, (float)(HW * xw)};                       // interior rows: (1/area, area)
         const uint64_t okmask = __builtin_amdgcn_ballot_w64(col_ok);     // lanes with an output
+        const bool il0 = comb_il() == 0;
         // stage 1: tile-2 column this lane's a_k, b_k go to -- its own tile column, or a padding column of the row when
         // that column is the left neighbour's halo (lane 0 of a comb of a strip with a neighbour) or the lane idles
-        const int jw = (comb_rho() < HW && !(pred && (lane & 15) == 0)) ? jt : SW + (lane & 15);
+        const int jw = (comb_rho() < HW && !(pred && comb_il() == 0)) ? jt : SW + (lane & 15);
         static_assert(SW + 16 <= P1 && P1 + SW + 16 <= RS, "padding columns behind both planes of a tile row");
 
         // ---- register state ------------------------------------------------------------------------------------
@@ -457,6 +468,12 @@ __global__ __launch_bounds__(NT, 5) void k_v5_walk(Args A) {
             ring[SL] = rv + ring[SLP];                     // colSum integral.cu:124-128
             f2 u;
             V5_BOX(u, SL, SL01);
+            if (L != 16 && k == 0) {
+                // combs that are not whole DPP rows get no zero fill: the first lane of a comb of strip 0 (its a/b
+                // columns 0 .. 8 are outputs) takes the box without left taps instead
+                const f2 u0 = ring[SL] - ring[SL01];
+                if (il0) u = u0;
+            }
             const f2 m = div_ca(u, area_of(BH * i - R + T, BORDERc));   // (mean_p, mean_Ip); no window sum of p, I p can be tiny (smx_agg_v5.h)
             const f2 g = gq[T];
             // compute_ak_and_bk guidedFilter.cu:345-354
@@ -686,7 +703,8 @@ struct PermArgs {
     unsigned* i2p[2];
 };
 __global__ __launch_bounds__(CLP) void k_v5_perm(PermArgs pa, int w, int h) {
-    const int cl = threadIdx.x, rho = cl >> 4, il = cl & 15;
+    const int cl = threadIdx.x, cw = cl >> 6, ln = cl & 63;
+    const int rho = ln / L < CPW ? CPW * cw + ln / L : HW, il = ln % L;
     const int k = blockIdx.x / h, y = blockIdx.x - k * h, v = blockIdx.y;
     const int x1 = OWS * k - R - 1 + HW * il + rho;     // a/b column of stage-1 comb lane cl
     const int xq = x1 - R;                              // q column of stage-2 comb lane cl
@@ -719,7 +737,7 @@ __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K
     if (e >= np) return;
     const int row = (int)(e / OWS), p = (int)(e - (size_t)row * OWS);   // row = k h + y
     const int k = row / h, y = row - k * h;
-    const int rho = p / 15, i1 = p - 15 * rho;
+    const int rho = p / (L - 1), i1 = p - (L - 1) * rho;
     const int x = OWS * k + HW * i1 + rho;
     if (x >= w) return;
     const float* __restrict__ q = wa.q[blockIdx.y] + e;
@@ -767,6 +785,8 @@ int v5_wta_launch(int nviews, const float* const* q, int64_t* const* keys, int w
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
+
+void v5_geometry(int* ow, int* bh) { *ow = v5::OWS; *bh = v5::BH; }
 
 bool v5_supported(const smx_params* p) {
     if (p->radius != v5::R) return false;

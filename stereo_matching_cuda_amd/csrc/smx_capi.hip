@@ -37,6 +37,7 @@ int v4_read_status(const void* d_ws, unsigned* out);
 void v4_geometry(int* ow, int* bh);
 // smx_agg_v5.hip
 bool v5_supported(const smx_params* p);
+void v5_geometry(int* ow, int* bh);
 
 // the fused aggregation; reports the path that ran: 2 = ring walker, 4 = FAST, 5 = comb walker
 static int aggregate_fused(int path, const smx_params* p, int nviews, const uint8_t* const* d_guide,
@@ -173,7 +174,7 @@ int smx_agg_geometry(int radius, int* strip_cols, int* band_rows, int* tile_cols
     smx_params p;
     smx_default_params(&p);
     p.radius = radius;
-    if (g_agg_path != 3 && g_agg_path != 4 && v5_supported(&p)) { ow = 285; bh = 10; }   // the comb walker (smx_agg_v5.h)
+    if (g_agg_path != 3 && g_agg_path != 4 && v5_supported(&p)) v5_geometry(&ow, &bh);   // the comb walker
     if (strip_cols) *strip_cols = ow;
     if (band_rows) *band_rows = bh;
     if (tile_cols) *tile_cols = ow + 2 * radius + 1;

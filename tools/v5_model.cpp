@@ -31,7 +31,10 @@ void orc_guided_filter(const orc_params*, const uint8_t*, const float*, float*, 
 void orc_init_wta(float*, float*, int64_t);
 }
 
-constexpr int R = 9, HW = 19, L = 16, NR = 19, SW = NR * L, OWS = HW * (L - 1), BH = 10, RD = 20;
+#ifndef MODEL_L
+#define MODEL_L 16
+#endif
+constexpr int R = 9, HW = 19, L = MODEL_L, NR = 19, SW = NR * L, OWS = HW * (L - 1), BH = 10, RD = 20;
 static const float NZ = -0.0f;
 
 struct f2 { float x, y; };
@@ -122,15 +125,20 @@ static void run_strip(int k, int K, int NI, const std::vector<Rec>* rin, std::ve
             }
         }
         // ---- X(i): comb lanes, LANE = one integral-image column
-        auto box = [&](std::vector<Lane>& ls, int lane, int slot, int slot01) {
+        auto box = [&](std::vector<Lane>& ls, int lane, int slot, int slot01, bool fix_first) {
             // S11 - S10 - S01 + S00 with the DPP row_shr:1 taps; lane i == 0 of a DPP row has no source lane:
             // the operation is skipped there
             const int il = lane % L;
             f2 u = ls[lane].ring[slot];
             // (zero-filled DPP source for lane i == 0: u - (+0), u + (+0))
-            if (il > 0) { u.x -= ls[lane - 1].ring[slot].x; u.y -= ls[lane - 1].ring[slot].y; } else { u.x -= 0.0f; u.y -= 0.0f; }
+            const float left0 = L == 16 ? 0.0f : NAN;          // row_shr:1 zero fill / wave_shr:1: whatever the lane in front holds
+            if (il > 0) { u.x -= ls[lane - 1].ring[slot].x; u.y -= ls[lane - 1].ring[slot].y; } else { u.x -= left0; u.y -= left0; }
             u.x -= ls[lane].ring[slot01].x; u.y -= ls[lane].ring[slot01].y;
-            if (il > 0) { u.x += ls[lane - 1].ring[slot01].x; u.y += ls[lane - 1].ring[slot01].y; } else { u.x += 0.0f; u.y += 0.0f; }
+            if (il > 0) { u.x += ls[lane - 1].ring[slot01].x; u.y += ls[lane - 1].ring[slot01].y; } else { u.x += left0; u.y += left0; }
+            // combs that are not whole DPP rows: the first lane of a comb of strip 0 (stage 1: it has outputs, columns
+            // 0 .. 8) takes the box without left taps instead
+            if (L != 16 && fix_first && il == 0)
+                u = f2{ls[lane].ring[slot].x - ls[lane].ring[slot01].x, ls[lane].ring[slot].y - ls[lane].ring[slot01].y};
             return u;
         };
         auto area_of = [&](int x, int y) {
@@ -147,7 +155,7 @@ static void run_strip(int k, int K, int NI, const std::vector<Rec>* rin, std::ve
                     l1[lane].ring[slot] = f2{rv.x + l1[lane].ring[slotp].x, rv.y + l1[lane].ring[slotp].y};
                 }
                 std::vector<f2> u(SW);
-                for (int lane = 0; lane < SW; ++lane) u[lane] = box(l1, lane, slot, slot01);   // ... then the taps
+                for (int lane = 0; lane < SW; ++lane) u[lane] = box(l1, lane, slot, slot01, k == 0);   // ... then the taps
                 for (int lane = 0; lane < SW; ++lane) {
                     const int y = y1 - R, x = base1 + lane_j(lane) - R;
                     f2 ab{NZ, NZ};
@@ -173,7 +181,7 @@ static void run_strip(int k, int K, int NI, const std::vector<Rec>* rin, std::ve
                     l2[lane].ring[slot] = f2{rv.x + l2[lane].ring[slotp].x, rv.y + l2[lane].ring[slotp].y};
                 }
                 std::vector<f2> u(SW);
-                for (int lane = 0; lane < SW; ++lane) u[lane] = box(l2, lane, slot, slot01);
+                for (int lane = 0; lane < SW; ++lane) u[lane] = box(l2, lane, slot, slot01, false);
                 for (int lane = 0; lane < SW; ++lane) {
                     const int il = lane % L;
                     const int y = y2 - R, x = base2 + lane_j(lane) - R;

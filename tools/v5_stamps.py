@@ -18,7 +18,7 @@ for _ in range(3):
     pipe.run(dl, dr)
 torch.cuda.synchronize()
 L = C.CDLL(os.environ["SMX_LIB_PATH"])
-NW, SW = 10, 6
+NW, SW = 8, 6
 NS = SW * 48
 buf = np.zeros(NW * NS, np.uint64)
 L.smx_debug_read_stamps5(buf.ctypes.data_as(C.c_void_p), buf.size)
