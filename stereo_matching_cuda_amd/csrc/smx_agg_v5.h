@@ -46,7 +46,7 @@ struct Args {
 };
 
 inline int strips(int w) { return (w + OWS - 1) / OWS; }
-inline int bands(int h) { return (h + 2 * 9 + BH - 1) / BH + 1; }     // the q rows of iteration i end at 10 i - 18
+inline int bands(int h) { return (h + 2 * 9 + BH - 1) / BH + 2; }     // the q rows of iteration i end at 10 i - 28
 inline size_t sv_hand_floats(int h) { return (size_t)2 * bands(h) * REC_U * 4; }   // parity x records
 
 }  // namespace v5

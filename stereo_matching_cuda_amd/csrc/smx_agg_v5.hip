@@ -100,26 +100,33 @@ constexpr int WHATIF = SMX_V5_WHATIF;
 __device__ float g_dump[2 * TILE_F + NT * 48];
 #endif
 
-// ---- DPP row_shr:1 with zero fill, fused into the arithmetic: lane i of a 16-lane row reads lane i-1 of `left`,
-// lane 0 reads +0.  (The compiler keeps a separate v_mov_b32_dpp per tap; the fused forms halve the box.)
-// s_nop 1: a VGPR written by the VALU instruction in front may not be read by DPP for two wait states, and the
-// compiler's hazard recogniser does not look into inline assembly.
-__device__ __forceinline__ float sub_left(float own, float left) {      // own - left[lane-1]
-    float d;
+// ---- DPP left taps fused into the arithmetic: lane i reads lane i-1 (`row_shr:1` with zero fill inside a 16-lane DPP row
+// for combs of 16, `wave_shr:1` otherwise).  (The compiler keeps a separate v_mov_b32_dpp per tap; the fused forms
+// halve the box.)  A VGPR written by the VALU instruction in front may not be read by DPP for two wait states and the
+// compiler's hazard recogniser does not look into inline assembly: box_bottom, whose sources are the column sums of
+// this very row, brings its own s_nop 1; box_top reads ring slots written 19 rows ago.
+#define V5_DPP_SHR "%s row_mask:0xf bank_mask:0xf bound_ctrl:1"
+__device__ __forceinline__ f2 box_bottom(f2 s) {            // s - s[lane-1], both components
+    f2 d;
     if (L == 16)
-        asm("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(left), "v"(own));
+        asm("s_nop 1\n\tv_subrev_f32_dpp %0, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_subrev_f32_dpp %1, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(d.x), "=&v"(d.y) : "v"(s.x), "v"(s.y));
     else
-        asm("s_nop 1\n\tv_subrev_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(left), "v"(own));
+        asm("s_nop 1\n\tv_subrev_f32_dpp %0, %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_subrev_f32_dpp %1, %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(d.x), "=&v"(d.y) : "v"(s.x), "v"(s.y));
     return d;
 }
-__device__ __forceinline__ float add_left(float own, float left) {      // own + left[lane-1]
-    float d;
+__device__ __forceinline__ f2 box_top(f2 u, f2 t) {         // u + t[lane-1], both components
+    f2 d;
     if (L == 16)
-        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(left), "v"(own));
+        asm("v_add_f32_dpp %0, %2, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %1, %3, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(d.x), "=&v"(d.y) : "v"(t.x), "v"(t.y), "v"(u.x), "v"(u.y));
     else
-        asm("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(d) : "v"(left), "v"(own));
+        asm("v_add_f32_dpp %0, %2, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %1, %3, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(d.x), "=&v"(d.y) : "v"(t.x), "v"(t.y), "v"(u.x), "v"(u.y));
     return d;
 }
+#undef V5_DPP_SHR
 
 // cost_pair of smx_agg_dev.h with the two truncations as v_min_f32 |d|, <scalar threshold>: the thresholds stay in
 // SGPRs (the generic form canonicalises them into VGPRs that then live through the whole kernel)
@@ -158,6 +165,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     __shared__ float rcp_s[RCP_N];                                  // RN(1/area)
     __shared__ int s_item, s_next;
     __shared__ unsigned s_seen;                                     // last value read from the left neighbour's flag
+    __shared__ unsigned s_x1;                                       // stage-2 waves that have taken their rows out of tile 2 (counts up through an item)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -180,22 +188,12 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         const int rho = comb_rho(), il = comb_il();
         return rho < HW ? HW * il + rho : 0;                        // (idle lanes run along on column 0)
     };
-    constexpr int NQROW = SW / 4;                                   // 76 quads per tile row
-    constexpr int NCT = NT - 64;                                    // 576 cost threads (waves 1..9)
-    constexpr int NQB = BH * NQROW - NCT;                           // 184 quads left for round B = 368 pairs
-    static_assert(NQB > 0 && 2 * NQB <= NCT, "two rounds cover the band");
-    // stage-1 input units of this thread (waves 1..9): round A one quad (tile row a_row, columns a_col ..+3),
-    // round B one pair (b_row, b_col, b_col+1); packed into one register: a_col | a_row << 9 | b_col << 13 |
-    // b_row << 22 | b_on << 26
-    unsigned cgeo;
-    {
-        const int ct = max(tid - 64, 0);
-        const int a_row = ct / NQROW, a_col = (ct - a_row * NQROW) * 4;
-        const int u = NCT + (ct >> 1), ur = u / NQROW;
-        const int b_row = min(ur, BH - 1), b_col = (u - ur * NQROW) * 4 + 2 * (ct & 1);
-        cgeo = (unsigned)a_col | (unsigned)a_row << 9 | (unsigned)b_col << 13 | (unsigned)b_row << 22 |
-               (ct < 2 * NQB ? 1u << 26 : 0u);
-    }
+    // stage-1 inputs (cost evaluation): done by the stage-1 waves that do not scan (waves 1 .. NS1-1), in the shadow of
+    // the row scans; NRQ rounds of one quad (four tile columns of one row) per thread, the last round almost full
+    constexpr int NQROW = SW / 4;                                   // quads per tile row (76 / 57)
+    constexpr int NCT = 64 * (NS1 - 1);                             // cost threads
+    constexpr int NQT = BH * NQROW;                                 // quads per band
+    constexpr int NRQ = (NQT + NCT - 1) / NCT;                      // rounds
 
     if (tid == 0) s_item = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
@@ -269,85 +267,67 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // use it), consumed row by row in X2
         f2 gq[ST2 ? 1 : BH];                 // stage 1: (mean_I, 1/(var+eps)) of the a/b rows
         unsigned gI[ST2 ? BH / 2 : 1];       // stage 2: guidance image values of two q rows each (fp16 pairs)
+        f2 r2[ST2 ? BH : 1];                 // stage 2: the band's (R2 a, R2 b) rows, taken out of tile 2 in X(i), used in R(i+1)
+#pragma unroll
+        for (int t = 0; t < (ST2 ? BH : 1); ++t) r2[t] = NZ2;
         f4 hreg = {0, 0, 0, 0};              // (stage-1 role, threads 0 .. REC_U-1) this thread's unit of the left neighbour's next record
         bool have_pref = false;
         unsigned seen = 0;
 
         // stage-1 input units of this thread (waves 1..9): round A one quad, round B one pair; tile offsets and the
         // byte offsets in the two image planes without the band term
-        struct CostGeo { int a_row, a_col, b_row, b_col; bool b_on; };
-        auto cost_geo = [&]() {
-            // (opaque: the unpacked fields and everything derived from them -- plane offsets, tile offsets -- are
-            // re-derived where they are used instead of being hoisted out of the band loop into long-lived registers)
-            CostGeo g;
-            const unsigned cg = (unsigned)opaque((int)cgeo);
-            g.a_col = (int)(cg & 511u);
-            g.a_row = (int)((cg >> 9) & 15u);
-            g.b_col = (int)((cg >> 13) & 511u);
-            g.b_row = (int)((cg >> 22) & 15u);
-            g.b_on = (cg >> 26) != 0;
-            return g;
+        // tile (row, column) of this thread's quad of round r; re-derived from the thread index where it is used (a few
+        // integer instructions) instead of living in registers through the comb rows
+        auto cost_unit = [&](int r, int& row, int& col, bool& on) {
+            const int u = r * NCT + opaque(tid) - 64;
+            on = u < NQT;
+            const int uc = min(u, NQT - 1);
+            row = uc / NQROW;
+            col = (uc - row * NQROW) * 4;
         };
-        // loads of the stage-1 inputs of band ib (rows clamped into the image: every load is issued): round-A raw quads
-        // and round-B raw pairs of the two images.  Locals of the phase that evaluates them: no register carries them on.
-        struct Raw { u4 ra, rb; u2 pa, pb; };
-        auto issue_cost = [&](int ib) {
-            Raw r;
-            const CostGeo g = cost_geo();
+        // Loads of the stage-1 inputs of band ib (rows clamped into the image: every load is issued) and their evaluation
+        // raw -> (p, I p) -> tile 1 buffer `dst`; cells outside the image are -0.  One phase: no register carries the raw
+        // values on.
+        auto eval_band = [&](int ib, float* dst) {
             auto off = [&](int row, int col, int dd) {
                 const int y = min(BH * ib + row, h - 1);
                 return (unsigned)(min(max(base1 + col + dd, -PADX), w) + PADX) * 4u + (unsigned)y * fgw4;
             };
-            r.ra = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(g.a_row, g.a_col, 0), o_fg1, 0);
-            r.rb = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(g.a_row, g.a_col, d), o_fg2, 0);
-            r.pa = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)off(g.b_row, g.b_col, 0), o_fg1, 0);
-            r.pb = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)off(g.b_row, g.b_col, d), o_fg2, 0);
-            return r;
-        };
-        // raw -> (p, I p) -> tile 1 buffer `dst` (band ib); cells outside the image are -0
-        auto eval_cost = [&](int ib, float* dst, const Raw& rw) {
-            const u4 ra = rw.ra, rb = rw.rb;
-            const u2 pa = rw.pa, pb = rw.pb;
-            const CostGeo g = cost_geo();
-            const bool edge = xedge || BH * ib + BH > h;
-            {
-                const unsigned r1[4] = {ra.x, ra.y, ra.z, ra.w}, r2[4] = {rb.x, rb.y, rb.z, rb.w};
-                float* p = dst + g.a_row * RS + g.a_col;
+            u4 ra[NRQ], rb[NRQ];
 #pragma unroll
-                for (int jj = 0; jj < 4; jj += 2) {
-                    f2 px, py;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        f2 v = cost_pair_s(__builtin_bit_cast(fg_t, r1[jj + j]), __builtin_bit_cast(fg_t, r2[jj + j]), cc);
-                        if (edge) {
-                            const int c = base1 + g.a_col + jj + j;
-                            if (!(c >= 0 && c < w && BH * ib + g.a_row < h)) v = NZ2;
-                        }
-                        px[j] = v.x; py[j] = v.y;
-                    }
-                    *(f2*)(p + jj) = px;
-                    *(f2*)(p + P1 + jj) = py;
-                }
+            for (int r = 0; r < NRQ; ++r) {
+                int row, col; bool on;
+                cost_unit(r, row, col, on);
+                ra[r] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(row, col, 0), o_fg1, 0);
+                rb[r] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(row, col, d), o_fg2, 0);
             }
-            if (g.b_on) {
-                const unsigned r1[2] = {pa.x, pa.y}, r2[2] = {pb.x, pb.y};
-                f2 px, py;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    f2 v = cost_pair_s(__builtin_bit_cast(fg_t, r1[j]), __builtin_bit_cast(fg_t, r2[j]), cc);
-                    if (edge) {
-                        const int c = base1 + g.b_col + j;
-                        if (!(c >= 0 && c < w && BH * ib + g.b_row < h)) v = NZ2;
-                    }
-                    px[j] = v.x; py[j] = v.y;
+            const bool edge = xedge || BH * ib + BH > h;
+            auto cell = [&](unsigned a, unsigned b, int row, int c) {
+                f2 v = cost_pair_s(__builtin_bit_cast(fg_t, a), __builtin_bit_cast(fg_t, b), cc);
+                if (edge) {
+                    const int ci = base1 + c;
+                    if (!(ci >= 0 && ci < w && BH * ib + row < h)) v = NZ2;
                 }
-                float* p = dst + g.b_row * RS + g.b_col;
-                *(f2*)p = px;
-                *(f2*)(p + P1) = py;
+                return v;
+            };
+#pragma unroll
+            for (int r = 0; r < NRQ; ++r) {
+                int row, col; bool on;
+                cost_unit(r, row, col, on);
+                const unsigned r1[4] = {ra[r].x, ra[r].y, ra[r].z, ra[r].w}, r2q[4] = {rb[r].x, rb[r].y, rb[r].z, rb[r].w};
+                float* p = dst + row * RS + col;
+                if (r + 1 < NRQ || on) {
+#pragma unroll
+                    for (int jj = 0; jj < 4; jj += 2) {
+                        const f2 v0 = cell(r1[jj], r2q[jj], row, col + jj), v1 = cell(r1[jj + 1], r2q[jj + 1], row, col + jj + 1);
+                        *(f2*)(p + jj) = (f2){v0.x, v1.x};
+                        *(f2*)(p + P1 + jj) = (f2){v0.y, v1.y};
+                    }
+                }
             }
         };
         // guidance of the output rows of iteration ib (rows clamped into the image: every load is issued)
-        auto issue_guid = [&](int ib) {
+        auto issue_guid = [&](int ib, int yq0) {
             if (WHATIF & 32) return;
             if constexpr (!ST2) {
 #pragma unroll
@@ -357,10 +337,10 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     gq[t] = __builtin_bit_cast(f2, g);
                 }
             } else {
-                // q rows 10 (ib-1) - 18 + 2 m, + 1: the first one is even, so a pair is one element of the row-pair plane
+                // q rows yq0 + 2 m, + 1: yq0 is even, so a pair is one element of the row-pair plane
 #pragma unroll
                 for (int m = 0; m < BH / 2; ++m) {
-                    const int yp = min(max((BH * (ib - 1) - 2 * R) / 2 + m, 0), (h - 1) / 2);
+                    const int yp = min(max(yq0 / 2 + m, 0), (h - 1) / 2);
                     gI[m] = ldu(r_fix, vg, o_i2p + yp * (CLP * 4));
                 }
             }
@@ -440,11 +420,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // (bottom taps) and SL01 (top taps, 19 rows up): left taps = lane i-1 of the DPP row
 #define V5_BOX(u, SL, SL01)                                    \
     do {                                                       \
-        u.x = sub_left(ring[SL].x, ring[SL].x);                \
-        u.y = sub_left(ring[SL].y, ring[SL].y);                \
+        u = box_bottom(ring[SL]);                              \
         u = u - ring[SL01];                                    \
-        u.x = add_left(u.x, ring[SL01].x);                     \
-        u.y = add_left(u.y, ring[SL01].y);                     \
+        u = box_top(u, ring[SL01]);                            \
     } while (0)
         // (1/area, area) of output row y for this lane (border bands: clipped window height, table look-up)
         auto area_of = [&](int y, auto BORDERc) {
@@ -491,15 +469,15 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             rv = rvn;
             __builtin_amdgcn_sched_barrier(0);
         };
-        // one comb row of stage 2 (a/b band i-1): ring slot of a/b row 10 (i-1) - 9 + T
-        auto row2 = [&](auto Nc, auto BORDERc, int i, const f2 (&r2)[BH]) {
+        // one comb row of stage 2, run in R(i) on the a/b band i-2 (same parity as i): ring slot of a/b row 10 (i-2) - 9 + T
+        auto row2 = [&](auto Nc, auto BORDERc, int i) {
             constexpr int N = decltype(Nc)::value, T = N % BH, PAR = N / BH;
-            constexpr int SL = (BH * (PAR ^ 1) + T + 11) % RD, SL01 = (SL + 1) % RD, SLP = (SL + RD - 1) % RD;
+            constexpr int SL = (BH * PAR + T + 11) % RD, SL01 = (SL + 1) % RD, SLP = (SL + RD - 1) % RD;
             constexpr bool BORDER = decltype(BORDERc)::value;
             ring[SL] = r2[T] + ring[SLP];
             f2 u;
             V5_BOX(u, SL, SL01);
-            const int yq = BH * (i - 1) - 2 * R + T;
+            const int yq = BH * (i - 2) - 2 * R + T;
             const f2 ca = area_of(yq, BORDERc);
             f2 m = div_ca(u, ca);
             // tiny (or zero) window sums of a, b take the true division (wave-uniform, rare); lanes without an
@@ -529,10 +507,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         }
         if constexpr (!ST2) fetch_rec(0);
         have_pref = pred;
-        if (wave != 0) {
-            const Raw rw = issue_cost(0);
-            eval_cost(0, tile1[0], rw);
-        }
+        if constexpr (!ST2) { if (wave != 0) eval_band(0, tile1[0]); }
 
         // hand-in of record `rec` (stage-1 role, strips with a left neighbour): stage-2 halo columns -> tile 2 (scanned
         // around in R(rec)), stage-1 row carries -> LDS
@@ -567,10 +542,16 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
 #endif
             // ------------------------------------ R(i) --------------------------------------------------
             V5_STAMP(0);
-            if (wave == 0) {
-                if (!(WHATIF & 1024)) __builtin_amdgcn_s_setprio(3);
-                if (!(WHATIF & 1)) rowscans(i, t1);
-                __builtin_amdgcn_s_setprio(0);
+            if constexpr (!ST2) {
+                if (wave == 0) {
+                    if (!(WHATIF & 1024)) __builtin_amdgcn_s_setprio(3);
+                    if (!(WHATIF & 1)) rowscans(i, t1);
+                    __builtin_amdgcn_s_setprio(0);
+                } else if (!(WHATIF & 2)) {
+                    // the stage-1 inputs of band i+1 -> the other tile-1 buffer, in the shadow of the row scans
+                    eval_band(i + 1, t1n);
+                }
+                issue_guid(i, 0);
             } else {
                 if (wave == NWAVE - 1 && lane == 63) {
                     // an otherwise idle lane looks at the left neighbour's flag for the prefetch of record i+1
@@ -579,17 +560,22 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     if (i == NI - 1)
                         s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                // stage-1 inputs of band i+1: loaded and evaluated here, in the shadow of the row scans (no register
-                // carries them through another phase)
-                if (!(WHATIF & 2)) {
-                    const Raw rw = issue_cost(i + 1);
-                    eval_cost(i + 1, t1n, rw);
+                // the comb rows of stage 2 on the a/b band i-2 (taken out of tile 2 in X(i-1)): in the shadow of the row scans
+                if (i >= 2) {
+                    const int yq0 = BH * (i - 2) - 2 * R;
+                    const bool border = yq0 < R + 1 || yq0 + BH - 1 > h - 1 - R;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(WHATIF & 8)) {
+#define V5_R2(TT, B) row2(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, i);
+                    if (border) { V5_R2(0, true) V5_R2(1, true) V5_R2(2, true) V5_R2(3, true) V5_R2(4, true) V5_R2(5, true) V5_R2(6, true) V5_R2(7, true) V5_R2(8, true) V5_R2(9, true) }
+                    else { V5_R2(0, false) V5_R2(1, false) V5_R2(2, false) V5_R2(3, false) V5_R2(4, false) V5_R2(5, false) V5_R2(6, false) V5_R2(7, false) V5_R2(8, false) V5_R2(9, false) }
+                    }
+#undef V5_R2
                 }
                 // every storing wave drains its global accesses before the barrier behind which one lane publishes
                 // the record stored in X(i-1)
-                if constexpr (ST2) drain_vmem();
+                drain_vmem();
             }
-            issue_guid(i);
             V5_STAMP(1);
             wg_barrier();
             V5_STAMP(2);
@@ -599,12 +585,12 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 wg_barrier();
             }
 #endif
-            // ------------------------------------ X1(i): stage 2 takes its rows out of tile 2 ----------------
+            // ------------------------------------ X(i) ---------------------------------------------------
             if (succ && tid == NT - 1 && i >= 1) flag_store(myflag, (unsigned)i);
             seen = s_seen;
-            f2 r2[ST2 ? BH : 1];
             f2 rv = NZ2;
             if constexpr (ST2) {
+                // stage 2 takes the a/b band i-1 (scanned in R(i)) out of tile 2: its comb rows run in R(i+1)
 #pragma unroll
                 for (int t = 0; t < BH; ++t) r2[t] = tile_rd(tile2 + t * RS + jt);
                 const int hq = hu_idx();
@@ -621,21 +607,28 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     }
                     st16_sc1(r_hand, (unsigned)(o_out + i * REC_U * 16) + (unsigned)hq * 16u, hov);
                 }
+                // this wave has what it needs from tile 2: tell the stage-1 waves, which overwrite it with the a_k, b_k of
+                // this band (a counter instead of a workgroup barrier: they rarely get there before it is complete)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r2[0]), "+v"(r2[1]), "+v"(r2[2]), "+v"(r2[3]), "+v"(r2[4]), "+v"(r2[5]),
+                             "+v"(r2[6]), "+v"(r2[7]), "+v"(r2[8]), "+v"(r2[9]) :: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&s_x1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                V5_STAMP(3);
+                V5_STAMP(4);
+                // guidance image values of the q rows of R(i+1)
+                issue_guid(i, BH * (i - 1) - 2 * R);
             } else {
                 // the left neighbour's record i+1 is needed at the end of this iteration: its load goes out now
                 // (unconditionally: a load under a condition is waited for where the branches merge); what it
                 // returns counts only if the record had been published
                 fetch_rec(min(i + 1, NI - 1));
                 rv = tile_rd(t1 + jt);
-            }
-            V5_STAMP(3);
-            wg_barrier();          // tile 2 is free: the a_k, b_k of this band go straight into it
-            V5_STAMP(4);
-            // ------------------------------------ X2(i): the comb rows ---------------------------------------
-            if constexpr (!ST2) {
+                V5_STAMP(3);
+                // tile 2 is free once every stage-2 wave has its rows: the a_k, b_k of this band go straight into it
+                const unsigned need = (unsigned)NS1 * (unsigned)(i + 1);
+                while (__hip_atomic_load(&s_x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+                V5_STAMP(4);
                 // an interior band: every window of its a/b rows is unclipped in y
                 const bool border = BH * i - R < R + 1 || BH * i - R + BH - 1 > h - 1 - R;
-                // (idle comb lanes -- the 20th DPP row -- run along on tile column 0: no branch around the loads)
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(WHATIF & 4)) {
 #define V5_R1(TT, B) row1(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, i, t1, rv);
@@ -643,18 +636,6 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 else { V5_R1(0, false) V5_R1(1, false) V5_R1(2, false) V5_R1(3, false) V5_R1(4, false) V5_R1(5, false) V5_R1(6, false) V5_R1(7, false) V5_R1(8, false) V5_R1(9, false) }
                 }
 #undef V5_R1
-            } else {
-                if (i >= 1) {
-                    const int yq0 = BH * (i - 1) - 2 * R;
-                    const bool border = yq0 < R + 1 || yq0 + BH - 1 > h - 1 - R;
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (!(WHATIF & 8)) {
-#define V5_R2(TT, B) row2(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, i, r2);
-                    if (border) { V5_R2(0, true) V5_R2(1, true) V5_R2(2, true) V5_R2(3, true) V5_R2(4, true) V5_R2(5, true) V5_R2(6, true) V5_R2(7, true) V5_R2(8, true) V5_R2(9, true) }
-                    else { V5_R2(0, false) V5_R2(1, false) V5_R2(2, false) V5_R2(3, false) V5_R2(4, false) V5_R2(5, false) V5_R2(6, false) V5_R2(7, false) V5_R2(8, false) V5_R2(9, false) }
-                    }
-#undef V5_R2
-                }
             }
             have_pref = pred && (seen == FLAG_DONE || seen >= (unsigned)i + 2u);
             // ---- hand-in of record i+1 (needed by R(i+1)): prefetched at the top of X1 if it had been published
@@ -681,6 +662,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             if (i + 1 < NI) band(std::integral_constant<int, 1>{}, i + 1);
         }
         };
+        if (tid == 0) s_x1 = 0u;        // (ordered before the first use by the barrier at the top of the first band)
         if (st2w) item_body(std::true_type{}); else item_body(std::false_type{});
         // the last record and the last q rows: drained, then published
         drain_vmem();
