@@ -10,10 +10,13 @@ a and b never leave the CU), running WTA of both views, (N > 1: one RCCL MIN all
 int64 keys, the disparity slices being sharded across ranks), decode, LR check, filling.  Inputs are
 resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-roofline: the aggregation operator (smx_dev_aggregate_wta_pair: left + right volume) against HBM:
-algorithmic bytes are 8 B per (pixel, disparity) cell of a volume (read raw cost 4 B + write/consume
-aggregated cost 4 B) x the cells one call processes (2 volumes), divided by the call's
-average device time, measured live with HIP events on the launch stream.
+roofline: the dominant kernel -- the fused aggregation walker (k_v5_walk / k_v4_walk: left + right volume in one
+launch) -- against HBM: algorithmic bytes are 8 B per (pixel, disparity) cell of a volume (read raw cost 4 B +
+write/consume aggregated cost 4 B) x the cells one launch processes (2 volumes), divided by the
+kernel's average launch duration, measured live over the timed region with HIP events recorded on the launch stream
+at the stage boundaries inside the C-ABI (smx_set_timing(2) / smx_stage_times).  `operator` repeats the figure for
+the whole smx_dev_aggregate_wta_pair call (key presets, guidance statistics, walker, WTA pass), which is what the
+lines of rounds 1-3 reported as `frac`.
 cpu_baseline: the CPU oracle (port of the reference kernels, 1 thread) timed on this box's host
 cores on the same pair -- a reported baseline, not the target.
 """
@@ -80,19 +83,25 @@ def main():
     local_slices = pipe.s_end - pipe.s_begin
 
     def step(events=None):
-        pipe.init_keys()
         if events is not None:
+            es = torch.cuda.Event(enable_timing=True)
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
+            ee = torch.cuda.Event(enable_timing=True)
+            es.record()
+        pipe.init_keys()
+        if events is not None:
             e0.record()
         pipe.aggregate_pair(dl, dr)   # both views per kernel launch
         if events is not None:
             e1.record()
-            events.append((e0, e1))
         if world > 1:
             from stereo_matching_cuda_amd.sharded import allreduce_min_keys_
             allreduce_min_keys_(pipe.keys)
         pipe.finish()
+        if events is not None:
+            ee.record()
+            events.append((es, e0, e1, ee))
 
     def fence():
         if world > 1:
@@ -104,37 +113,56 @@ def main():
     fence()
     pipe.check_status()       # a timed-out hand-off would invalidate everything that follows
     events = []
+    import ctypes as C
+    from stereo_matching_cuda_amd import _lib
+    smx.check(smx.lib().smx_set_timing(2))      # stage events of every call of the timed region (no synchronisation)
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(events)
     fence()
     dt = time.perf_counter() - t0
+    stage = _lib.StageMs()
+    stage_rc = smx.lib().smx_stage_times(C.byref(stage))
+    smx.check(smx.lib().smx_set_timing(0))
     pipe.check_status()       # ... and the status word is per call: read it before the next call clears it
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    agg_ms = [a.elapsed_time(b) for a, b in events]
+    def spread(v):
+        v = sorted(v)
+        return {"median": v[len(v) // 2], "min": v[0], "max": v[-1], "mean": sum(v) / len(v)} if v else None
+
+    agg_ms = [e0.elapsed_time(e1) for _, e0, e1, _ in events]
+    step_ms = [es.elapsed_time(ee) for es, _, _, ee in events]
     agg_avg_s = (sum(agg_ms) / max(1, len(agg_ms))) * 1e-3
     cells_per_call = 2.0 * w * h * local_slices   # left + right volume
-    achieved = ALGO_BYTES_PER_CELL * cells_per_call / agg_avg_s / 1e9 if agg_avg_s > 0 else 0.0
+    operator_achieved = ALGO_BYTES_PER_CELL * cells_per_call / agg_avg_s / 1e9 if agg_avg_s > 0 else 0.0
+    # the walker kernel alone: its launches between the stage events of the C-ABI, summed over the timed region
+    # (chunked workspaces: several launches per call, each over its share of the cells)
+    ncalls = max(1, stage.calls) if stage_rc == 0 else 0
+    walk_avg_s = stage.aggregation / ncalls * 1e-3 if ncalls else 0.0
+    achieved = ALGO_BYTES_PER_CELL * cells_per_call / walk_avg_s / 1e9 if walk_avg_s > 0 else operator_achieved
 
     # HBM bytes of one aggregation call from the committed PMC profile of this same command
     # (tools/pmc.sh + tools/traffic.py; FETCH_SIZE/WRITE_SIZE in separate passes, gfx950 x2 fetch
     # correction calibrated on a kernel with a known byte count).  Only valid for the profiled config.
     traffic = None
     traffic_src = None
-    tname = {"kitti": "r03_traffic.json", "motorcycle": "r03_motorcycle_traffic.json",
-             "4k": "r03_4k_traffic.json"}.get(args.workload) if args.mode == "exact" else None
+    tname = {"kitti": "r04_traffic.json", "motorcycle": "r04_motorcycle_traffic.json",
+             "4k": "r04_4k_traffic.json"}.get(args.workload) if args.mode == "exact" else None
     tpath = os.path.join(ROOT, "profiles", tname) if tname else None
     if world == 1 and tpath and args.slices_in_flight is None and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic = float(tj["aggregation_call_hbm_bytes"])
+            # the profile belongs to one build of the library: a stale file is not quoted
+            if tj.get("library") != smx.lib().smx_version().decode():
+                raise KeyError("library")
+            traffic = float(tj["walker_hbm_bytes"])
             traffic_src = (f"profiles/{tname}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command in "
-                           "separate passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 summed over the kernels of one call "
+                           "separate passes, (2*FETCH_SIZE + WRITE_SIZE)*1024 of the walker kernel per launch "
                            "(tools/gpu_suite.sh, tools/traffic.py); an UPPER bound: the x2 FETCH_SIZE rule of the "
                            "guide over-counts narrow loads")
         except (ValueError, KeyError):
@@ -159,17 +187,28 @@ def main():
                    "width": w, "height": h, "disparities": D,
                    "sharding": f"disparity slices / {world} ranks" if world > 1 else "none",
                    "slices_in_flight": pipe.slices_in_flight, "library": smx.lib().smx_version().decode()},
+        "step_ms": spread(step_ms),
         "roofline": {
             "bound": "hbm",
-            "kernel": "guided-filter aggregation + WTA of both views (smx_dev_aggregate_wta_pair)",
+            "kernel": "fused guided-filter aggregation walker, both views per launch (k_v5_walk; k_v4_walk where the comb "
+                      "walker does not apply)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
             "traffic_source": traffic_src,
-            "avg_launch_ms": agg_avg_s * 1e3,
+            "avg_launch_ms": walk_avg_s * 1e3,
             "algorithmic_bytes_per_launch": ALGO_BYTES_PER_CELL * cells_per_call,
+            "stage_ms_per_call": ({k: getattr(stage, k) / ncalls for k in ("guidance", "aggregation", "wta", "finish")}
+                                  if ncalls else None),
+            "operator": {
+                "what": "the whole smx_dev_aggregate_wta_pair call (guidance statistics, walker, WTA pass): the `frac` of "
+                        "the round 1-3 lines",
+                "call_ms": spread(agg_ms),
+                "achieved": operator_achieved,
+                "frac": operator_achieved / HBM_PEAK_GBS,
+            },
         },
     }
 

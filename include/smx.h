@@ -239,10 +239,22 @@ int smx_dev_finish_pair(const smx_params* p, const int64_t* d_keys, int w, int h
 int64_t smx_pack_key(float cost, uint32_t slice);
 void smx_unpack_key(int64_t key, float* cost, uint32_t* slice);
 
-/* Cumulative device time (ms) of the aggregation kernels launched by the most recent
- * smx_dev_aggregate_wta call on this thread when timing was enabled with
- * smx_set_timing(1); measured with hipEvents on the caller's stream (synchronises). */
-int smx_set_timing(int enable);
+/* Per-stage device time (ms) of the calling thread's most recent timed call -- smx_dev_aggregate_wta[_pair]
+ * (+ a following smx_dev_finish_pair) or smx_ctx_stereo_pair -- when timing was enabled with smx_set_timing(1):
+ * HIP events of the device the call ran on, recorded on its stream at the stage boundaries (the reference prints
+ * one wall-clock `duration`, main.cu:52-54,156,184).  smx_stage_times synchronises with the last event.
+ *   upload / download: host <-> device copies of smx_ctx_stereo_pair;  guidance: key presets, image planes,
+ *   guidance statistics (guidedFilter.cu:58-123);  aggregation: the fused walker (or the multi-kernel passes);
+ *   wta: the packed-key pass over the aggregated planes;  finish: decode, LR check, filling (main.cu:112-155).
+ * smx_set_timing: 0 off, 1 the times of the LAST call, 2 cumulative over every call since it was switched on
+ * (`calls` counts them; up to 4096 stage marks, later ones are dropped). */
+typedef struct smx_stage_ms {
+    float upload, guidance, aggregation, wta, finish, download, total;
+    int calls;
+} smx_stage_ms;
+int smx_set_timing(int mode);
+int smx_stage_times(smx_stage_ms* out);
+/* guidance + aggregation + wta of that call, and its kernel launches */
 int smx_last_agg_ms(float* ms, int* launches);
 
 #pragma GCC visibility pop

@@ -33,6 +33,11 @@ class Params(C.Structure):
                 ("radius", C.c_int), ("eps", C.c_double), ("d_lr", C.c_int)]
 
 
+class StageMs(C.Structure):
+    _fields_ = [(k, C.c_float) for k in ("upload", "guidance", "aggregation", "wta", "finish", "download", "total")] + \
+               [("calls", C.c_int)]
+
+
 class PairOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "best_l", "best_r", "dmap_l", "dmap_r", "mean_l", "mean_r", "occlusion", "filled",
@@ -90,6 +95,7 @@ SIGNATURES = {
     "smx_agg_geometry": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "smx_set_timing": (_i, [_i]),
     "smx_last_agg_ms": (_i, [C.POINTER(_f), C.POINTER(_i)]),
+    "smx_stage_times": (_i, [C.POINTER(StageMs)]),
 }
 
 _lib = None

@@ -1493,6 +1493,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             ++nl;
         }
     }
+    stage_mark(ST_GUIDANCE, st);
 
     v4::Args a0;
     memset(&a0, 0, sizeof(a0));
@@ -1546,6 +1547,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         } else if (fast) rc = use_cost ? launch_walk4<v4::SRC_COST, true>(a, st) : launch_walk4<v4::SRC_IMG, true>(a, st);
         else rc = use_cost ? launch_walk4<v4::SRC_COST, false>(a, st) : launch_walk4<v4::SRC_IMG, false>(a, st);
         if (rc) return rc;
+        stage_mark(ST_WALK, st);
         bool al8 = L.plane % 2 == 0;
         for (int v = 0; v < nviews; ++v) al8 = al8 && ((uintptr_t)wa.q[v] & 7) == 0;
         if (use_v5 && own_q) {
@@ -1557,6 +1559,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             hipLaunchKernelGGL(v4::k_v4_wta, dim3(cdivu4((int64_t)L.plane, 256), nviews), dim3(256), 0, st, wa,
                                L.plane, cnt, s0);
         SMX_HIP(hipGetLastError());
+        stage_mark(ST_WTA, st);
         nl += s0 != s_begin ? 3 : 2;
     }
     if (launches) *launches = nl;

@@ -713,35 +713,54 @@ struct Wta5Args {
     const float* q[2];
     int64_t* keys[2];
 };
+// EPL = elements per lane: 2 (8-byte loads; needs an even strip row OWS... the rows are OWS = 209 floats, so pairs
+// are taken over the whole plane: K h OWS even and 8-byte aligned planes) or 1
+template <int EPL>
 __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K, int count, int slice0) {
     const size_t np = (size_t)K * h * OWS;
-    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= np) return;
-    const int row = (int)(e / OWS), p = (int)(e - (size_t)row * OWS);   // row = k h + y
-    const int k = row / h, y = row - k * h;
-    const int rho = p / (L - 1), i1 = p - (L - 1) * rho;
-    const int x = OWS * k + HW * i1 + rho;
-    if (x >= w) return;
-    const float* __restrict__ q = wa.q[blockIdx.y] + e;
-    int64_t* kp = wa.keys[blockIdx.y] + (size_t)y * w + x;
-    int64_t key = *kp;
+    const size_t e0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * EPL;
+    if (e0 >= np) return;
+    const float* __restrict__ q = wa.q[blockIdx.y] + e0;
+    int64_t* const keys = wa.keys[blockIdx.y];
+    // the pixels of this lane's elements (once per call)
+    int64_t* kp[EPL];
+    int64_t key[EPL];
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) {
+        const size_t e = e0 + j;
+        const int row = (int)(e / OWS), p = (int)(e - (size_t)row * OWS);   // row = k h + y
+        const int k = row / h, y = row - k * h;
+        const int rho = p / (L - 1), i1 = p - (L - 1) * rho;
+        const int x = OWS * k + HW * i1 + rho;
+        kp[j] = e < np && x < w ? keys + (size_t)y * w + x : nullptr;
+        key[j] = kp[j] ? *kp[j] : KEY_IDENTITY;
+    }
+    typedef float fv __attribute__((ext_vector_type(EPL)));
     int z = 0;
     constexpr int U = 8;
     for (; z + U <= count; z += U) {
-        float v[U];
+        fv v[U];
 #pragma unroll
-        for (int t = 0; t < U; ++t) v[t] = __builtin_nontemporal_load(&q[(size_t)(z + t) * np]);
+        for (int t = 0; t < U; ++t) v[t] = __builtin_nontemporal_load((const fv*)&q[(size_t)(z + t) * np]);
 #pragma unroll
-        for (int t = 0; t < U; ++t) {
-            const int64_t kk = pack_key(v[t], (uint32_t)(slice0 + z + t));
-            key = kk < key ? kk : key;
-        }
+        for (int t = 0; t < U; ++t)
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const int64_t kk = pack_key(EPL == 1 ? v[t][0] : v[t][j], (uint32_t)(slice0 + z + t));
+                key[j] = kk < key[j] ? kk : key[j];
+            }
     }
     for (; z < count; ++z) {
-        const int64_t kk = pack_key(__builtin_nontemporal_load(&q[(size_t)z * np]), (uint32_t)(slice0 + z));
-        key = kk < key ? kk : key;
+        const fv v = __builtin_nontemporal_load((const fv*)&q[(size_t)z * np]);
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const int64_t kk = pack_key(EPL == 1 ? v[0] : v[j], (uint32_t)(slice0 + z));
+            key[j] = kk < key[j] ? kk : key[j];
+        }
     }
-    *kp = key;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j)
+        if (kp[j]) *kp[j] = key[j];
 }
 
 }  // namespace v5
@@ -762,8 +781,14 @@ int v5_wta_launch(int nviews, const float* const* q, int64_t* const* keys, int w
     for (int v = 0; v < 2; ++v) { wa.q[v] = q[v < nviews ? v : 0]; wa.keys[v] = keys[v < nviews ? v : 0]; }
     const int K = v5::strips(w);
     const size_t np = (size_t)K * h * v5::OWS;
-    hipLaunchKernelGGL(v5::k_v5_wta, dim3((unsigned)((np + 255) / 256), (unsigned)nviews), dim3(256), 0, st, wa, w, h, K,
-                       count, slice0);
+    bool al8 = np % 2 == 0;
+    for (int v = 0; v < nviews; ++v) al8 = al8 && ((uintptr_t)wa.q[v] & 7) == 0;
+    if (al8)
+        hipLaunchKernelGGL(v5::k_v5_wta<2>, dim3((unsigned)((np / 2 + 255) / 256), (unsigned)nviews), dim3(256), 0, st, wa, w, h,
+                           K, count, slice0);
+    else
+        hipLaunchKernelGGL(v5::k_v5_wta<1>, dim3((unsigned)((np + 255) / 256), (unsigned)nviews), dim3(256), 0, st, wa, w, h, K,
+                           count, slice0);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

@@ -11,10 +11,30 @@
 namespace smx {
 
 static thread_local std::string g_err;
-static thread_local bool g_timing = false;
-static thread_local hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
-static thread_local bool g_ev_valid = false;
+static thread_local int g_timing = 0;        // 0 off, 1 the last call, 2 cumulative over calls
 static thread_local int g_launches = 0;
+// Stage timing of the calling thread (smx_set_timing / smx_stage_times): a list of (stage, event) marks of the
+// last timed call; the time between two consecutive marks belongs to the stage of the later one.  Events are taken
+// from a pool per device (an event records on the device that was current when it was created).
+struct StageTimer {
+    struct Mark { int stage; hipEvent_t ev; };
+    std::vector<Mark> marks;
+    std::vector<std::vector<hipEvent_t>> pool;   // [device] -> events
+    std::vector<size_t> used;                    // [device] -> events handed out for the current call
+    void begin() { marks.clear(); for (auto& u : used) u = 0; }
+    hipEvent_t get() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+        if ((size_t)dev >= pool.size()) { pool.resize(dev + 1); used.resize(dev + 1, 0); }
+        if (used[dev] == pool[dev].size()) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            pool[dev].push_back(e);
+        }
+        return pool[dev][used[dev]++];
+    }
+};
+static thread_local StageTimer g_timer;
 #ifndef SMX_DEFAULT_AGG_PATH
 #define SMX_DEFAULT_AGG_PATH 0
 #endif
@@ -56,6 +76,15 @@ static int aggregate_fused(int path, const smx_params* p, int nviews, const uint
     return SMX_OK;
 }
 
+void stage_mark(int stage, hipStream_t st) {
+    if (!g_timing) return;
+    if (stage == ST_BEGIN && g_timing == 1) g_timer.begin();
+    if (g_timer.marks.size() >= 4096) return;
+    hipEvent_t e = g_timer.get();
+    if (!e || hipEventRecord(e, st) != hipSuccess) return;
+    g_timer.marks.push_back({stage, e});
+}
+
 int fail(int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
@@ -93,7 +122,7 @@ void smx_default_params(smx_params* p) {
 
 const char* smx_last_error(void) { return g_err.c_str(); }
 
-const char* smx_version(void) { return "smx-hip gfx950 0.4 (fused guided-filter aggregation, three workgroups per CU)"; }
+const char* smx_version(void) { return "smx-hip gfx950 0.5 (comb walker: DPP box taps, register rings, two 512-thread workgroups per CU)"; }
 
 int smx_device_count(void) {
     int n = 0;
@@ -109,22 +138,38 @@ void smx_unpack_key(int64_t key, float* cost, uint32_t* slice) {
     if (slice) *slice = s;
 }
 
-int smx_set_timing(int enable) {
-    g_timing = enable != 0;
-    if (g_timing && !g_ev0) {
-        SMX_HIP(hipEventCreate(&g_ev0));
-        SMX_HIP(hipEventCreate(&g_ev1));
+int smx_set_timing(int mode) {
+    if (mode < 0 || mode > 2) return fail(SMX_E_ARG, "smx_set_timing: mode must be 0, 1 or 2");
+    g_timing = mode;
+    g_timer.begin();
+    return SMX_OK;
+}
+
+int smx_stage_times(smx_stage_ms* out) {
+    SMX_ARG(out);
+    memset(out, 0, sizeof(*out));
+    if (g_timer.marks.size() < 2) return fail(SMX_E_ARG, "smx_stage_times: no timed call recorded (smx_set_timing(1) first)");
+    SMX_HIP(hipEventSynchronize(g_timer.marks.back().ev));
+    float acc[ST_COUNT] = {0};
+    int calls = g_timer.marks.front().stage == ST_BEGIN ? 1 : 0;
+    for (size_t i = 1; i < g_timer.marks.size(); ++i) {
+        if (g_timer.marks[i].stage == ST_BEGIN) { ++calls; continue; }     // (the gap in front of a call is nobody's)
+        float t = 0;
+        SMX_HIP(hipEventElapsedTime(&t, g_timer.marks[i - 1].ev, g_timer.marks[i].ev));
+        acc[g_timer.marks[i].stage] += t;
     }
-    g_ev_valid = false;
+    out->calls = calls;
+    out->upload = acc[ST_UPLOAD]; out->guidance = acc[ST_GUIDANCE]; out->aggregation = acc[ST_WALK];
+    out->wta = acc[ST_WTA]; out->finish = acc[ST_FINISH]; out->download = acc[ST_DOWNLOAD];
+    out->total = out->upload + out->guidance + out->aggregation + out->wta + out->finish + out->download;
     return SMX_OK;
 }
 
 int smx_last_agg_ms(float* ms, int* launches) {
-    if (!g_ev_valid) return fail(SMX_E_ARG, "smx_last_agg_ms: no timed aggregation recorded");
-    SMX_HIP(hipEventSynchronize(g_ev1));
-    float t = 0;
-    SMX_HIP(hipEventElapsedTime(&t, g_ev0, g_ev1));
-    if (ms) *ms = t;
+    smx_stage_ms t;
+    int rc = smx_stage_times(&t);
+    if (rc) return rc;
+    if (ms) *ms = t.guidance + t.aggregation + t.wta;
     if (launches) *launches = g_launches;
     return SMX_OK;
 }
@@ -245,12 +290,16 @@ int smx_dev_finish_pair(const smx_params* p, const int64_t* d_keys, int w, int h
     const int64_t n = (int64_t)w * h;
     int rc;
     // one launch (a row per workgroup) where the row fits the LDS three times, else the three kernels
-    if (finish_pair_row_supported(w) && d_filled != d_occlusion)
-        return launch_finish_pair_row(p, d_keys, w, h, dminl, dminr, dOcclusion, vMin, d_best, d_dmap, d_occlusion,
-                                      d_filled, st);
-    if ((rc = launch_finish_keys(d_keys, n, dminl, dminr, d_best, d_dmap, d_occlusion, st))) return rc;
-    if ((rc = launch_detect_occlusion(p, d_occlusion, d_dmap + n, dOcclusion, w, h, st))) return rc;
-    return launch_fill_occlusion(d_occlusion, d_filled, w, h, vMin, st);
+    if (finish_pair_row_supported(w) && d_filled != d_occlusion) {
+        rc = launch_finish_pair_row(p, d_keys, w, h, dminl, dminr, dOcclusion, vMin, d_best, d_dmap, d_occlusion,
+                                    d_filled, st);
+    } else {
+        if ((rc = launch_finish_keys(d_keys, n, dminl, dminr, d_best, d_dmap, d_occlusion, st))) return rc;
+        if ((rc = launch_detect_occlusion(p, d_occlusion, d_dmap + n, dOcclusion, w, h, st))) return rc;
+        rc = launch_fill_occlusion(d_occlusion, d_filled, w, h, vMin, st);
+    }
+    stage_mark(ST_FINISH, st);
+    return rc;
 }
 
 int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uint8_t* d_other,
@@ -262,20 +311,16 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
     SMX_ARG(w >= 2 && h >= 1 && s_begin >= 0 && s_end >= s_begin && p->radius >= 0);
     { int rcd = check_same_device(d_workspace, "smx_dev_aggregate_wta"); if (rcd) return rcd; }
     hipStream_t st = (hipStream_t)stream;
+    stage_mark(ST_BEGIN, st);
     // fused path: radius <= 9; cost built on the fly or read from d_cost
     const bool can_fuse = v4_supported(p);
     if (g_agg_path >= 2 && !can_fuse)
         return fail(SMX_E_ARG, "smx_dev_aggregate_wta: fused path forced but radius > 9");
     if (can_fuse && g_agg_path != 1) {
         g_launches = 0;
-        if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
         int rc2 = aggregate_fused(g_agg_path, p, 1, &d_guide, &d_other, &d_cost, w, h, &dmin, s_begin, s_end, &d_keys,
                                &d_mean_u8, &d_agg, d_workspace, workspace_bytes, st, &g_launches);
         if (rc2) return rc2;
-        if (g_timing) {
-            SMX_HIP(hipEventRecord(g_ev1, st));
-            g_ev_valid = true;
-        }
         return SMX_OK;
     }
     g_last_path = 1;
@@ -316,12 +361,12 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
 
     int rc;
     g_launches = 0;
-    if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
     // guidance statistics (guidedFilter.cu:58-123)
     if ((rc = launch_guid_prep(d_guide, im, g1, n, st))) return rc;
     if ((rc = launch_integral(2, im, g1, g0, g1, w, h, 1, st))) return rc;
     if ((rc = launch_guid_finish(p, g0, g1, mean_im, cinv, d_mean_u8, w, h, st))) return rc;
     g_launches += 4;
+    stage_mark(ST_GUIDANCE, st);
     // slice loop (guidedFilter.cu:171-238), `chunk` slices per pass
     for (int s0 = s_begin; s0 < s_end; s0 += chunk) {
         const int cnt = (s_end - s0) < chunk ? (s_end - s0) : chunk;
@@ -336,10 +381,7 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
         float* agg = d_agg ? d_agg + (int64_t)(s0 - s_begin) * n : nullptr;
         if ((rc = launch_q_wta(p, A, B, im, d_keys, agg, w, h, cnt, s0, st))) return rc;
         g_launches += 6;
-    }
-    if (g_timing) {
-        SMX_HIP(hipEventRecord(g_ev1, st));
-        g_ev_valid = true;
+        stage_mark(ST_WALK, st);      // (this path folds the WTA into its last pass)
     }
     return SMX_OK;
 }
@@ -352,6 +394,7 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
     SMX_ARG(w >= 2 && h >= 1 && s_begin >= 0 && s_end >= s_begin && p->radius >= 0);
     { int rcd = check_same_device(d_workspace, "smx_dev_aggregate_wta_pair"); if (rcd) return rcd; }
     hipStream_t st = (hipStream_t)stream;
+    stage_mark(ST_BEGIN, st);
     const int64_t n = (int64_t)w * h;
     const int64_t vol = n * (s_end - s_begin);
     if (v4_supported(p) && g_agg_path != 1) {
@@ -362,15 +405,10 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
         uint8_t* mean[2] = {d_mean_u8, d_mean_u8 ? d_mean_u8 + n : nullptr};
         float* agg[2] = {d_agg, d_agg ? d_agg + vol : nullptr};
         g_launches = 0;
-        if (g_timing) SMX_HIP(hipEventRecord(g_ev0, st));
         int rc2 = aggregate_fused(g_agg_path, p, 2, guide, other, nullptr, w, h, dmin, s_begin, s_end, keys,
                                d_mean_u8 ? mean : nullptr, d_agg ? agg : nullptr, d_workspace,
                                workspace_bytes, st, &g_launches);
         if (rc2) return rc2;
-        if (g_timing) {
-            SMX_HIP(hipEventRecord(g_ev1, st));
-            g_ev_valid = true;
-        }
         return SMX_OK;
     }
     if (g_agg_path >= 2)
@@ -601,8 +639,10 @@ int smx_ctx_stereo_pair(smx_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r
     if (want_cost && !c->costL.p) { SMX_HIP(c->costL.alloc(vb)); SMX_HIP(c->costR.alloc(vb)); }
     if (want_agg && !c->aggLR.p) SMX_HIP(c->aggLR.alloc(2 * vb));
     uint8_t* dL = c->dL.as<uint8_t>(); uint8_t* dR = c->dR.as<uint8_t>();
+    stage_mark(ST_BEGIN, st);
     SMX_HIP(hipMemcpyAsync(dL, gray_l, n, hipMemcpyHostToDevice, st));
     SMX_HIP(hipMemcpyAsync(dR, gray_r, n, hipMemcpyHostToDevice, st));
+    stage_mark(ST_UPLOAD, st);
     int rc;
     const int64_t nn = (int64_t)n;
     float* bestL = c->best.as<float>(); float* bestR = bestL + n;
@@ -654,6 +694,7 @@ int smx_ctx_stereo_pair(smx_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r
     };
     for (auto& cp : copies)
         if (cp.dst && cp.src) SMX_HIP(hipMemcpyAsync(cp.dst, cp.src, cp.b, hipMemcpyDeviceToHost, st));
+    stage_mark(ST_DOWNLOAD, st);
     SMX_HIP(hipStreamSynchronize(st));
     return smx_dev_agg_status(c->ws.p);
 }

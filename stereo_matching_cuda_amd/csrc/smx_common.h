@@ -48,6 +48,11 @@ inline CostConst make_cost_const(const smx_params* p) {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Stage boundary of the calling thread's timed call (smx_set_timing(1) / smx_stage_times): records a HIP event of the
+// CURRENT device on `st`; a no-op when timing is off.  Stage ids: smx_capi.hip.
+enum StageId { ST_BEGIN = 0, ST_UPLOAD, ST_GUIDANCE, ST_WALK, ST_WTA, ST_FINISH, ST_DOWNLOAD, ST_COUNT };
+void stage_mark(int stage, hipStream_t st);
+
 // ---- packed WTA key ---------------------------------------------------------------------
 // key = sord(cost) << 32 | (0xFFFFFFFF - slice), compared as SIGNED 64-bit integers: sord = monotone
 // f32 -> i32 (-0 folded to +0), so that the per-pixel reduction of the shards is a plain int64 MIN

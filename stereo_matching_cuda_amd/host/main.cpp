@@ -163,6 +163,8 @@ int main(int argc, char** argv) {
     }
 
     const std::clock_t t_begin = std::clock();
+    bool have_stage_ms = false;
+    smx_stage_ms stage_ms = {};
     Pair in;
     if (!load_pair(left, right, in)) {
         std::fprintf(stderr, "cannot load an RGB pair of equal size from %s / %s\n", left.c_str(),
@@ -228,6 +230,7 @@ int main(int argc, char** argv) {
         smx_ctx* ctx = nullptr;
         if (sh_create) CHECK(sh_create(&smx_config().params, w, h, size_d, opt.ngpu, opt.overlap ? 1 : 0, &sctx));
         else CHECK(smx_create(&smx_config().params, w, h, size_d, &ctx));
+        if (!sh_create) CHECK(smx_set_timing(1));     // per-stage device times of the last pair (smx_stage_times)
         auto run_pair = [&]() {
             return sh_create ? sh_run(sctx, gray[0], gray[1], dmin[0], dmin[1], &out)
                              : smx_ctx_stereo_pair(ctx, gray[0], gray[1], dmin[0], dmin[1], &out);
@@ -239,6 +242,14 @@ int main(int argc, char** argv) {
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             std::printf("pairs %d on one context: %.3f ms per pair, uploads and downloads included\n", opt.pairs - 1,
                         ms / (opt.pairs - 1));
+        }
+        if (!sh_create) {
+            smx_stage_ms t;
+            if (smx_stage_times(&t) == SMX_OK) {
+                have_stage_ms = true;
+                stage_ms = t;
+            }
+            CHECK(smx_set_timing(0));
         }
         if (sh_create) CHECK(sh_destroy(sctx));
         else CHECK(smx_destroy(ctx));
@@ -288,6 +299,11 @@ int main(int argc, char** argv) {
     }
 
     std::cout << "duration: " << duration << std::endl;
+    // (the reference prints one wall-clock duration, main.cu:184; the device time of the last pair by stage goes beside it)
+    if (have_stage_ms)
+        std::printf("device ms of the last pair: upload %.3f, guidance %.3f, aggregation %.3f, wta %.3f, finish %.3f, "
+                    "download %.3f, total %.3f\n", stage_ms.upload, stage_ms.guidance, stage_ms.aggregation, stage_ms.wta,
+                    stage_ms.finish, stage_ms.download, stage_ms.total);
     std::cout << "Free the memory ..." << std::endl;
     for (int v = 0; v < 2; ++v) { std::free(gray[v]); std::free(in.rgb[v]); }
     if (write_failures) {
