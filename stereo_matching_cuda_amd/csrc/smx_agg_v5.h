@@ -8,9 +8,10 @@ namespace v5 {
 
 // Comb length: 16 = one comb per 16-lane DPP row, five comb waves per stage, 640-thread workgroups (only one of
 // which fits a CU: 3 + 3 + 2 + 2 waves per SIMD at 96 VGPRs); 12 = five combs per wave, four comb waves per stage,
-// 512-thread workgroups (two waves per SIMD each: two per CU at 128 VGPRs)
+// 512-thread workgroups (two waves per SIMD each: two per CU at 128 VGPRs); 9 = seven combs per wave, three comb
+// waves per stage + a row-scan wave + a cost wave (512 threads): the row scans run beside the comb rows (PIPE)
 #ifndef SMX_V5_L
-#define SMX_V5_L 12
+#define SMX_V5_L 9
 #endif
 constexpr int L = SMX_V5_L;             // lanes of a comb
 constexpr int CPW = 64 / L;             // combs per wave
@@ -20,6 +21,7 @@ constexpr int BH = 10;                  // band height
 constexpr int REC_U = 105;              // 16-byte units per hand-off record
 constexpr int WG_PER_CU = 2;
 constexpr int CLP = 64 * NS1;           // comb lane slots per stage and strip
+constexpr bool PIPE = L == 9;           // dedicated scan and cost waves, one workgroup barrier per band
 
 struct Args {
     // the fixed part of the workspace: both image planes [h][w + 2 PADX] of k_v4_prep and the guidance planes
@@ -47,7 +49,8 @@ struct Args {
 
 inline int strips(int w) { return (w + OWS - 1) / OWS; }
 inline int bands(int h) { return (h + 2 * 9 + BH - 1) / BH + 2; }     // the q rows of iteration i end at 10 i - 28
-inline size_t sv_hand_floats(int h) { return (size_t)2 * bands(h) * REC_U * 4; }   // parity x records
+inline int records(int h) { return bands(h) + 2; }                   // hand-off records per (strip boundary, slice-view)
+inline size_t sv_hand_floats(int h) { return (size_t)2 * records(h) * REC_U * 4; }   // parity x records
 
 }  // namespace v5
 

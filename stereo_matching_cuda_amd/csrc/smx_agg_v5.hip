@@ -50,12 +50,16 @@ namespace v5 {
 using namespace aggdev;
 
 constexpr int R = 9, HW = 2 * R + 1;
-constexpr int SW = HW * L;              // integral-image columns per strip = tile columns (304 / 228)
-static_assert(OWS == HW * (L - 1) && SW == OWS + HW && SW % 4 == 0 && CPW * L <= 64 && CPW * NS1 >= HW, "strip geometry");
+constexpr int SWU = HW * L;             // integral-image columns per strip (304 / 228 / 171)
+constexpr int SW = (SWU + 3) / 4 * 4;   // tile columns: whole quads (the columns behind SWU are never used)
+static_assert(OWS == HW * (L - 1) && SWU == OWS + HW && CPW * L <= 64 && CPW * NS1 >= HW, "strip geometry");
 constexpr int RD = 20;                  // ring slots (>= 2R+2; a multiple of BH: static slots)
 static_assert(RD % BH == 0 && RD >= HW + 1, "ring");
-constexpr int NWAVE = 2 * NS1, NT = 64 * NWAVE;      // 640 / 512 threads
+constexpr int NX = PIPE ? 2 : 0;                    // PIPE: a row-scan wave and a cost wave beside the comb waves
+constexpr int NWAVE = 2 * NS1 + NX, NT = 64 * NWAVE;   // 640 / 512 / 512 threads
 constexpr int WPE = NWAVE == 8 ? 4 : 5;             // waves per SIMD the register budget is set for (128 / 96 VGPRs)
+constexpr int NT1 = PIPE ? 3 : 2, NT2 = PIPE ? 2 : 1;  // tile buffers per stage
+enum Role { ROLE_S1 = 0, ROLE_S2 = 1, ROLE_SCAN = 2, ROLE_COST = 3 };
 // A tile row is component-planar: first components (p / a) at [0, 304), second ones (I p / b) at [P1, P1 + 304):
 // the row scan moves four columns of one component per LDS instruction, a comb lane reads its cell's pair with
 // one ds_read2st64_b32 (offset1 = P1 / 64).
@@ -93,6 +97,14 @@ __device__ unsigned long long g_stamps[10 * STAMP_SLOTS];
 #define SMX_V5_WHATIF 0
 #endif
 constexpr int WHATIF = SMX_V5_WHATIF;
+#ifndef SMX_V5_EVAL_S1
+#define SMX_V5_EVAL_S1 0
+#endif
+#ifndef SMX_V5_WMAP
+#define SMX_V5_WMAP 0
+#endif
+constexpr bool EVAL_S1 = SMX_V5_EVAL_S1;
+constexpr int WMAP = SMX_V5_WMAP;
 
 #ifdef SMX_V5_DUMP
 // Diagnostic build only: tile 1 (current buffer), tile 2 and the comb registers of one item behind the barrier that
@@ -152,6 +164,14 @@ __device__ __forceinline__ f2 div_ca(f2 x, f2 ca) {
     return m;
 }
 
+__device__ __forceinline__ f2 div_ca_q(f2 x, f2 ca) { f2 q; asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(q) : "v"(x), "v"(ca)); return q; }
+__device__ __forceinline__ f2 div_ca_e(f2 q, f2 x, f2 ca) {
+    f2 e;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(e) : "v"(q), "v"(ca), "v"(x));
+    return e;
+}
+__device__ __forceinline__ f2 div_ca_m(f2 e, f2 q, f2 ca) { f2 m; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(m) : "v"(e), "v"(ca), "v"(q)); return m; }
+
 // a cell's (first, second) component of a tile row (the compiler forms ds_read2st64_b32 / ds_write2st64_b32:
 // the planes are 5 x 64 dwords apart)
 __device__ __forceinline__ f2 tile_rd(const float* p) { return (f2){p[0], p[P1]}; }
@@ -159,23 +179,27 @@ __device__ __forceinline__ void tile_wr(float* p, f2 v) { p[0] = v.x; p[P1] = v.
 
 template <int DUMMY>
 __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
-    __shared__ __attribute__((aligned(16))) float tile1[2][TILE_F];
-    __shared__ __attribute__((aligned(16))) float tile2[TILE_F];
-    __shared__ float cin1[BH][2];                                   // stage-1 row carries of the current band
+    __shared__ __attribute__((aligned(16))) float tile1[NT1][TILE_F];
+    __shared__ __attribute__((aligned(16))) float tile2s[NT2][TILE_F];
+    __shared__ float cin1s[2][BH][2];                               // stage-1 row carries of the band the next scan pass takes (PIPE: by pass parity)
     __shared__ float rcp_s[RCP_N];                                  // RN(1/area)
     __shared__ int s_item, s_next;
     __shared__ unsigned s_seen;                                     // last value read from the left neighbour's flag
+    __shared__ unsigned s_peek[2];                                  // PIPE: the flag as peeked at during slot sl -> [(sl + 1) & 1], read by every wave at the top of slot sl + 1
     __shared__ unsigned s_x1;                                       // stage-2 waves that have taken their rows out of tile 2 (counts up through an item)
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int hwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // role of a hardware wave (waves w and w + 4 of a workgroup share a SIMD)
+    const int wave = PIPE && WMAP == 1 ? (int)((0x75436210u >> (4 * hwave)) & 7u) : hwave;
+    const int tid = 64 * wave + lane;
     const int w = A.w, h = A.h, K = A.K, NI = A.NI, nsv = A.nsv;
     const CostConst cc = A.cc;
     const f2 NZ2 = {-0.0f, -0.0f};
     if (tid < RCP_N) rcp_s[tid] = kRcp.v[tid];
 
     // ---- comb geometry of this thread: stage, DPP row = residue, position in the comb, tile column ----------
-    const bool st2w = wave >= NS1;
+    const bool st2w = wave >= NS1 && wave < 2 * NS1;
     // (per-lane values that only one phase of an iteration needs are re-derived from the thread index where they
     // are used -- a handful of integer instructions per band -- instead of living in VGPRs through the comb rows)
     // comb of this lane = residue rho (>= 19: the lane idles), position il in the comb
@@ -191,9 +215,12 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     // stage-1 inputs (cost evaluation): done by the stage-1 waves that do not scan (waves 1 .. NS1-1), in the shadow of
     // the row scans; NRQ rounds of one quad (four tile columns of one row) per thread, the last round almost full
     constexpr int NQROW = SW / 4;                                   // quads per tile row (76 / 57)
-    constexpr int NCT = 64 * (NS1 - 1);                             // cost threads
+    constexpr int NCT = PIPE ? 64 : 64 * (NS1 - 1);                 // cost threads (PIPE: the cost wave)
+    constexpr int NRB = 4;                                          // rounds whose loads are in flight together
+    // PIPE: the comb waves of both stages take one quad per thread (quads 0 .. NCT2-1: stage 2 first), the cost wave the rest
+    constexpr int NCT2 = PIPE ? (EVAL_S1 ? 2 : 1) * 64 * NS1 : 0;
     constexpr int NQT = BH * NQROW;                                 // quads per band
-    constexpr int NRQ = (NQT + NCT - 1) / NCT;                      // rounds
+    constexpr int NRQ = (NQT - NCT2 + NCT - 1) / NCT;               // rounds
 
     if (tid == 0) s_item = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
@@ -217,7 +244,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // this strip's rows of the comb-ordered guidance planes
         const int o_g1p = (int)(A.o_g1p[view] + (unsigned)k * (unsigned)h * (CLP * 8u)),
                   o_i2p = (int)(A.o_i2p[view] + (unsigned)k * (unsigned)((h + 1) / 2) * (CLP * 4u));
-        const unsigned recb = (unsigned)NI * REC_U * 16u;        // bytes per (parity, slice-view)
+        const unsigned recb = (unsigned)(NI + 2) * REC_U * 16u;  // bytes per (parity, slice-view)  (smx_agg_v5.h records())
         const rsrc_t r_hand = mk_rsrc(A.hand, (size_t)2 * nsv * recb);
         const int o_in = (int)((((unsigned)(k - 1) & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
         const int o_out = (int)((((unsigned)k & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
@@ -227,8 +254,13 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
 
         // the strip has columns outside the image (virtual: -0)
         const bool xedge = base1 < 0 || base1 + SW > w;
-        auto item_body = [&](auto ST2c) {
-        constexpr bool ST2 = decltype(ST2c)::value;
+        auto item_body = [&](auto ROLEc) {
+        constexpr int ROLE = decltype(ROLEc)::value;
+        constexpr bool ST2 = ROLE == ROLE_S2, COMB = ROLE <= ROLE_S2;
+        // the tile-2 buffer the comb rows of stage 1 write / the next scan pass takes for stage 2 and the hand-in fills,
+        // and the stage-1 carries of that pass (PIPE: they alternate from band to band)
+        float* tile2 = tile2s[0];
+        float (*cin1)[2] = cin1s[0];
         // ---- per-lane constants of the item that every comb row needs ------------------------------------------
         const int jt = comb_jt();                                   // tile column
         int xw;                                                     // window width of this lane's output column
@@ -257,15 +289,15 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         static_assert(SW + 16 <= P1 && P1 + SW + 16 <= RS, "padding columns behind both planes of a tile row");
 
         // ---- register state ------------------------------------------------------------------------------------
-        f2 ring[RD];                         // ring[y mod RD] = S[y] of this lane's column; the slot of row y-1 is the running sum
+        f2 ring[COMB ? RD : 1];              // ring[y mod RD] = S[y] of this lane's column; the slot of row y-1 is the running sum
 #pragma unroll
-        for (int s = 0; s < RD; ++s) ring[s] = (f2){0.0f, 0.0f};
-        ring[ST2 ? 10 : RD - 1] = NZ2;   // the slot in front of the first row (stage 1: row 0; stage 2: row -9)
+        for (int s = 0; s < (COMB ? RD : 1); ++s) ring[s] = (f2){0.0f, 0.0f};
+        if constexpr (COMB) ring[ST2 ? 10 : RD - 1] = NZ2;   // the slot in front of the first row (stage 1: row 0; stage 2: row -9)
         // (arrays of the other role shrink to one element: the two roles are separate instantiations, so that no
         // register carries state of the other role around the band loop)
         // guidance of the band's output rows: loaded at the end of R (a barrier and the X1 phase ahead of the rows that
         // use it), consumed row by row in X2
-        f2 gq[ST2 ? 1 : BH];                 // stage 1: (mean_I, 1/(var+eps)) of the a/b rows
+        f2 gq[ROLE == ROLE_S1 ? BH : 1];     // stage 1: (mean_I, 1/(var+eps)) of the a/b rows
         unsigned gI[ST2 ? BH / 2 : 1];       // stage 2: guidance image values of two q rows each (fp16 pairs)
         f2 r2[ST2 ? BH : 1];                 // stage 2: the band's (R2 a, R2 b) rows, taken out of tile 2 in X(i), used in R(i+1)
 #pragma unroll
@@ -279,7 +311,8 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // tile (row, column) of this thread's quad of round r; re-derived from the thread index where it is used (a few
         // integer instructions) instead of living in registers through the comb rows
         auto cost_unit = [&](int r, int& row, int& col, bool& on) {
-            const int u = r * NCT + opaque(tid) - 64;
+            const int u = PIPE && ROLE == ROLE_S2 ? opaque(tid) - 64 * NS1 : PIPE && ROLE == ROLE_S1 ? 64 * NS1 + opaque(tid)
+                          : NCT2 + r * NCT + (PIPE ? opaque(lane) : opaque(tid) - 64);
             on = u < NQT;
             const int uc = min(u, NQT - 1);
             row = uc / NQROW;
@@ -287,20 +320,12 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         };
         // Loads of the stage-1 inputs of band ib (rows clamped into the image: every load is issued) and their evaluation
         // raw -> (p, I p) -> tile 1 buffer `dst`; cells outside the image are -0.  One phase: no register carries the raw
-        // values on.
+        // values on.  The loads of NRB rounds are in flight together.
         auto eval_band = [&](int ib, float* dst) {
             auto off = [&](int row, int col, int dd) {
                 const int y = min(BH * ib + row, h - 1);
                 return (unsigned)(min(max(base1 + col + dd, -PADX), w) + PADX) * 4u + (unsigned)y * fgw4;
             };
-            u4 ra[NRQ], rb[NRQ];
-#pragma unroll
-            for (int r = 0; r < NRQ; ++r) {
-                int row, col; bool on;
-                cost_unit(r, row, col, on);
-                ra[r] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(row, col, 0), o_fg1, 0);
-                rb[r] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(row, col, d), o_fg2, 0);
-            }
             const bool edge = xedge || BH * ib + BH > h;
             auto cell = [&](unsigned a, unsigned b, int row, int c) {
                 f2 v = cost_pair_s(__builtin_bit_cast(fg_t, a), __builtin_bit_cast(fg_t, b), cc);
@@ -311,32 +336,78 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 return v;
             };
 #pragma unroll
-            for (int r = 0; r < NRQ; ++r) {
-                int row, col; bool on;
-                cost_unit(r, row, col, on);
-                const unsigned r1[4] = {ra[r].x, ra[r].y, ra[r].z, ra[r].w}, r2q[4] = {rb[r].x, rb[r].y, rb[r].z, rb[r].w};
-                float* p = dst + row * RS + col;
-                if (r + 1 < NRQ || on) {
+            for (int r0 = 0; r0 < NRQ; r0 += NRB) {
+                constexpr int NB = NRB;
+                u4 ra[NB], rb[NB];
 #pragma unroll
-                    for (int jj = 0; jj < 4; jj += 2) {
-                        const f2 v0 = cell(r1[jj], r2q[jj], row, col + jj), v1 = cell(r1[jj + 1], r2q[jj + 1], row, col + jj + 1);
-                        *(f2*)(p + jj) = (f2){v0.x, v1.x};
-                        *(f2*)(p + P1 + jj) = (f2){v0.y, v1.y};
+                for (int q = 0; q < NB; ++q) {
+                    if (r0 + q < NRQ) {
+                        int row, col; bool on;
+                        cost_unit(r0 + q, row, col, on);
+                        ra[q] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(row, col, 0), o_fg1, 0);
+                        rb[q] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(row, col, d), o_fg2, 0);
                     }
                 }
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    if (r0 + q < NRQ) {
+                        int row, col; bool on;
+                        cost_unit(r0 + q, row, col, on);
+                        const unsigned r1[4] = {ra[q].x, ra[q].y, ra[q].z, ra[q].w}, r2q[4] = {rb[q].x, rb[q].y, rb[q].z, rb[q].w};
+                        float* p = dst + row * RS + col;
+                        if (r0 + q + 1 < NRQ || on) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj += 2) {
+                                const f2 v0 = cell(r1[jj], r2q[jj], row, col + jj), v1 = cell(r1[jj + 1], r2q[jj + 1], row, col + jj + 1);
+                                *(f2*)(p + jj) = (f2){v0.x, v1.x};
+                                *(f2*)(p + P1 + jj) = (f2){v0.y, v1.y};
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        // PIPE, comb roles: this thread's one quad of band ib -- loads at the start of the slot, evaluation behind the comb rows
+        auto eval_issue = [&](int ib, u4& ra, u4& rb) {
+            int row, col; bool on;
+            cost_unit(0, row, col, on);
+            const int y = min(BH * ib + row, h - 1);
+            auto off = [&](int dd) { return (unsigned)(min(max(base1 + col + dd, -PADX), w) + PADX) * 4u + (unsigned)y * fgw4; };
+            ra = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(0), o_fg1, 0);
+            rb = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(d), o_fg2, 0);
+        };
+        auto eval_finish = [&](int ib, float* dst, u4 ra, u4 rb) {
+            int row, col; bool on;
+            cost_unit(0, row, col, on);
+            const bool edge = xedge || BH * ib + BH > h;
+            const unsigned r1[4] = {ra.x, ra.y, ra.z, ra.w}, r2q[4] = {rb.x, rb.y, rb.z, rb.w};
+            float* p = dst + row * RS + col;
+#pragma unroll
+            for (int jj = 0; jj < 4; jj += 2) {
+                f2 v[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    v[j] = cost_pair_s(__builtin_bit_cast(fg_t, r1[jj + j]), __builtin_bit_cast(fg_t, r2q[jj + j]), cc);
+                    if (edge) {
+                        const int ci = base1 + col + jj + j;
+                        if (!(ci >= 0 && ci < w && BH * ib + row < h)) v[j] = NZ2;
+                    }
+                }
+                *(f2*)(p + jj) = (f2){v[0].x, v[1].x};
+                *(f2*)(p + P1 + jj) = (f2){v[0].y, v[1].y};
             }
         };
         // guidance of the output rows of iteration ib (rows clamped into the image: every load is issued)
         auto issue_guid = [&](int ib, int yq0) {
             if (WHATIF & 32) return;
-            if constexpr (!ST2) {
+            if constexpr (ROLE == ROLE_S1) {
 #pragma unroll
                 for (int t = 0; t < BH; ++t) {
                     const int y = min(max(BH * ib - R + t, 0), h - 1);
                     const u2 g = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)vg, o_g1p + y * (CLP * 8), 0);
                     gq[t] = __builtin_bit_cast(f2, g);
                 }
-            } else {
+            } else if constexpr (ST2) {
                 // q rows yq0 + 2 m, + 1: yq0 is even, so a pair is one element of the row-pair plane
 #pragma unroll
                 for (int m = 0; m < BH / 2; ++m) {
@@ -370,16 +441,17 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         };
 
         // ---- row scans of iteration i (wave 0): lanes 0..19 stage 1, lanes 32..51 stage 2; lane = (row, component)
-        auto rowscans = [&](int i, float* t1) {
+        // stage 1: band i1 in tile t1p; stage 2: the a/b band i2 (rows 10 i2 - 9 ..) in tile t2p
+        auto rowscans = [&](int i1, int i2, float* t1p, float* t2p, float (*cinp)[2]) {
             const int sc_l = lane & 31, sc_st = lane >> 5, sc_row = sc_l % BH, sc_comp = sc_l / BH;
-            const int y = sc_st == 0 ? BH * i + sc_row : BH * (i - 1) - R + sc_row;
-            const bool act = sc_l < 2 * BH && y >= 0 && y < h && (sc_st == 0 || i >= 1);
+            const int y = sc_st == 0 ? BH * i1 + sc_row : BH * i2 - R + sc_row;
+            const bool act = sc_l < 2 * BH && y >= 0 && y < h && (sc_st == 0 ? i1 >= 0 : i2 >= 0);
             if (!act) return;
-            float* const row = (sc_st == 0 ? t1 : tile2) + sc_row * RS + sc_comp * P1;
+            float* const row = (sc_st == 0 ? t1p : t2p) + sc_row * RS + sc_comp * P1;
             // stage 1 starts from the left neighbour's running row sum (or -0); stage 2 of a strip with a left
             // neighbour leaves the 19 halo columns alone and starts behind them from the halo's last column
             const bool keep = sc_st == 1 && pred;
-            float acc = (sc_st == 0 && pred) ? cin1[sc_row][sc_comp] : -0.0f;
+            float acc = (sc_st == 0 && pred) ? cinp[sc_row][sc_comp] : -0.0f;
             f4* const r4 = (f4*)row;
             constexpr int NG = SW / 4;
 #ifndef SMX_V5_SCAN_PF
@@ -439,18 +511,20 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // One comb row of stage 1: T = row of the band, N = T + 10 * (band parity) = ring slot of its image row.
         // rv = this row's (R1 p, R1 Ip) pair, read from the tile one row ahead; rows are separate scheduling regions
         // (the compiler otherwise runs the ten column sums first and keeps every tap of the band alive).
-        auto row1 = [&](auto Nc, auto BORDERc, int i, const float* t1, f2& rv) {
+        auto row1 = [&](auto Nc, auto MODEc, int i, const float* t1, f2& rv) {
             constexpr int N = decltype(Nc)::value, T = N % BH, SL = N, SL01 = (N + 1) % RD, SLP = (N + RD - 1) % RD;
-            constexpr bool BORDER = decltype(BORDERc)::value;
+            constexpr int MODE = decltype(MODEc)::value;     // 0: interior band of an interior strip (straight-line code);
+            constexpr bool BORDER = MODE == 2;               // 1: interior band, strip 0 or one with columns outside the image; 2: border band
+            const std::integral_constant<bool, BORDER> BORDERc;
             const f2 rvn = tile_rd(t1 + (T + 1 < BH ? T + 1 : T) * RS + jt);
             ring[SL] = rv + ring[SLP];                     // colSum integral.cu:124-128
             f2 u;
             V5_BOX(u, SL, SL01);
-            if (L != 16 && k == 0) {
+            if (L != 16 && MODE != 0) {
                 // combs that are not whole DPP rows get no zero fill: the first lane of a comb of strip 0 (its a/b
                 // columns 0 .. 8 are outputs) takes the box without left taps instead
                 const f2 u0 = ring[SL] - ring[SL01];
-                if (il0) u = u0;
+                if (il0 && k == 0) u = u0;
             }
             const f2 m = div_ca(u, area_of(BH * i - R + T, BORDERc));   // (mean_p, mean_Ip); no window sum of p, I p can be tiny (smx_agg_v5.h)
             const f2 g = gq[T];
@@ -461,13 +535,13 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             const float bk = 1.0f * m.x - mb2;
             // a/b row 10 i - 9 + T -> tile 2 (scanned in R(i+1)); rows / columns outside the image: -0
             f2 ab = {ak, bk};
-            if (BORDER || xedge) {
+            if (MODE != 0) {
                 const int ya = BH * i - R + T;
                 if (!(col_ok && ya >= 0 && ya < h)) ab = NZ2;
             }
             tile_wr(tile2 + T * RS + jw, ab);
             rv = rvn;
-            __builtin_amdgcn_sched_barrier(0);
+            if (T & 1) __builtin_amdgcn_sched_barrier(0);    // (regions of two rows: the second fills the wait states of the first)
         };
         // one comb row of stage 2, run in R(i) on the a/b band i-2 (same parity as i): ring slot of a/b row 10 (i-2) - 9 + T
         auto row2 = [&](auto Nc, auto BORDERc, int i) {
@@ -495,26 +569,96 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             const float qv = tq + m.y;
             if (!(WHATIF & 16) && (!BORDER || (yq >= 0 && yq < h)))
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qv), r_q, (int)vo, q_row0 + yq * q_pitch, AUX_NT);
+            if (T & 1) __builtin_amdgcn_sched_barrier(0);
+        };
+
+        // Two comb rows of stage 1 at once, interior band of an interior strip (MODE 0 of row1): the two dependent chains
+        // interleaved by hand, so that neither the wait states behind a packed operation nor the s_nop in front of a DPP
+        // read stay empty.  N0 = ring slot of the first row (even).
+        auto rows1_pair = [&](auto N0c, int i, const float* t1, f2& rv) {
+            constexpr int N0 = decltype(N0c)::value, T0 = N0 % BH;
+            constexpr int SLa = N0, SLb = N0 + 1, SLPa = (N0 + RD - 1) % RD, S01a = (N0 + 1) % RD, S01b = (N0 + 2) % RD;
+            const f2 rvb = tile_rd(t1 + (T0 + 1) * RS + jt);
+            const f2 rvn = tile_rd(t1 + (T0 + 2 < BH ? T0 + 2 : T0 + 1) * RS + jt);
+            const f2 old_a = ring[S01a];               // (slot S01a == SLb: the top taps of row a are what row b overwrites)
+            ring[SLa] = rv + ring[SLPa];               // colSum integral.cu:124-128
+            f2 ua = box_bottom(ring[SLa]);
+            const f2 sb = rvb + ring[SLa];
+            ua = ua - old_a;
+            f2 ub = box_bottom(sb);
+            ua = box_top(ua, old_a);
+            ring[SLb] = sb;
+            ub = ub - ring[S01b];
+            const f2 qa = div_ca_q(ua, ca_i);
+            ub = box_top(ub, ring[S01b]);
+            const f2 ea = div_ca_e(qa, ua, ca_i);
+            const f2 qb = div_ca_q(ub, ca_i);
+            const f2 ma = div_ca_m(ea, qa, ca_i);      // (mean_p, mean_Ip)
+            const f2 eb = div_ca_e(qb, ub, ca_i);
+            const f2 ga = gq[T0], gb = gq[T0 + 1];
+            const float mma = ga.x * ma.x;             // compute_ak_and_bk guidedFilter.cu:345-354
+            const f2 mb = div_ca_m(eb, qb, ca_i);
+            const float ta = ma.y - mma;
+            const float mmb = gb.x * mb.x;
+            const float aka = 1.0f * ta * ga.y;
+            const float tb = mb.y - mmb;
+            const float mb2a = 1.0f * ga.x * aka;
+            const float akb = 1.0f * tb * gb.y;
+            const float bka = 1.0f * ma.x - mb2a;
+            const float mb2b = 1.0f * gb.x * akb;
+            tile_wr(tile2 + T0 * RS + jw, (f2){aka, bka});
+            const float bkb = 1.0f * mb.x - mb2b;
+            tile_wr(tile2 + (T0 + 1) * RS + jw, (f2){akb, bkb});
+            rv = rvn;
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // the same for stage 2 (interior band); one vote on tiny window sums for both rows
+        auto rows2_pair = [&](auto N0c, int i) {
+            constexpr int N0 = decltype(N0c)::value, T0 = N0 % BH, PAR = N0 / BH;
+            constexpr int SLa = (BH * PAR + T0 + 11) % RD, SLb = (SLa + 1) % RD, SLPa = (SLa + RD - 1) % RD, S01a = SLb, S01b = (SLb + 1) % RD;
+            const f2 old_a = ring[S01a];
+            ring[SLa] = r2[T0] + ring[SLPa];
+            f2 ua = box_bottom(ring[SLa]);
+            const f2 sb = r2[T0 + 1] + ring[SLa];
+            ua = ua - old_a;
+            f2 ub = box_bottom(sb);
+            ua = box_top(ua, old_a);
+            ring[SLb] = sb;
+            ub = ub - ring[S01b];
+            const f2 qa = div_ca_q(ua, ca_i);
+            ub = box_top(ub, ring[S01b]);
+            const f2 ea = div_ca_e(qa, ua, ca_i);
+            const f2 qb = div_ca_q(ub, ca_i);
+            f2 ma = div_ca_m(ea, qa, ca_i);
+            const f2 eb = div_ca_e(qb, ub, ca_i);
+            float amin;
+            asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(amin) : "v"(ua.x), "v"(ua.y), "v"(ub.x));
+            f2 mb = div_ca_m(eb, qb, ca_i);
+            asm("v_min_f32 %0, %1, |%2|" : "=v"(amin) : "v"(amin), "v"(ub.y));
+            if ((__builtin_amdgcn_ballot_w64(!(amin >= 0x1p-100f)) & okmask) != 0) {
+                asm volatile("; exact-division slow path");
+                ma.x = 1.0f * ua.x / ca_i.y; ma.y = 1.0f * ua.y / ca_i.y;
+                mb.x = 1.0f * ub.x / ca_i.y; mb.y = 1.0f * ub.y / ca_i.y;
+            }
+            const fg_t ip = __builtin_bit_cast(fg_t, gI[T0 / 2]);
+            const int yq = BH * (i - 2) - 2 * R + T0;
+            const float tqa = ma.x * (float)ip.x;      // compute_q guidedFilter.cu:363-369
+            const float tqb = mb.x * (float)ip.y;
+            const float qva = tqa + ma.y;
+            const float qvb = tqb + mb.y;
+            if (!(WHATIF & 16)) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qva), r_q, (int)vo, q_row0 + yq * q_pitch, AUX_NT);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qvb), r_q, (int)vo, q_row0 + (yq + 1) * q_pitch, AUX_NT);
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
 
-        // ===================================== the band loop ==============================================
-        // prologue: stage-1 inputs of band 0 -> tile 1[0]; guidance of the first rows; the left neighbour's record 0
-        if (pred) {
-            if (tid == 0) spin_pred(1u);
-            wg_barrier();
-            seen = s_seen;
-        }
-        if constexpr (!ST2) fetch_rec(0);
-        have_pref = pred;
-        if constexpr (!ST2) { if (wave != 0) eval_band(0, tile1[0]); }
-
         // hand-in of record `rec` (stage-1 role, strips with a left neighbour): stage-2 halo columns -> tile 2 (scanned
         // around in R(rec)), stage-1 row carries -> LDS
-        auto hand_in = [&](int rec) {
+        auto hand_in = [&](bool halo) {
             const int hq = hu_idx();
             if (hq >= 0 && hq < NHU) {
-                if (rec >= 1) {
+                if (halo) {
                     const int t = hq / 10, j = (hq - 10 * t) * 2;
                     float* dst = tile2 + t * RS + j;
                     dst[0] = hreg.x;
@@ -527,7 +671,20 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 cin1[2 * tp + 1][0] = hreg.z; cin1[2 * tp + 1][1] = hreg.w;
             }
         };
-        if constexpr (!ST2) { if (pred) hand_in(0); }
+
+        if constexpr (!PIPE) {
+        // ===================================== the band loop ==============================================
+        // prologue: stage-1 inputs of band 0 -> tile 1[0]; guidance of the first rows; the left neighbour's record 0
+        if (pred) {
+            if (tid == 0) spin_pred(1u);
+            wg_barrier();
+            seen = s_seen;
+        }
+        if constexpr (!ST2) fetch_rec(0);
+        have_pref = pred;
+        if constexpr (!ST2) { if (wave != 0) eval_band(0, tile1[0]); }
+
+        if constexpr (!ST2) { if (pred) hand_in(false); }
 
         auto band = [&](auto PARc, int i) {
             constexpr int PAR = decltype(PARc)::value;
@@ -545,7 +702,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             if constexpr (!ST2) {
                 if (wave == 0) {
                     if (!(WHATIF & 1024)) __builtin_amdgcn_s_setprio(3);
-                    if (!(WHATIF & 1)) rowscans(i, t1);
+                    if (!(WHATIF & 1)) rowscans(i, i - 1, t1, tile2, cin1);
                     __builtin_amdgcn_s_setprio(0);
                 } else if (!(WHATIF & 2)) {
                     // the stage-1 inputs of band i+1 -> the other tile-1 buffer, in the shadow of the row scans
@@ -567,10 +724,12 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(WHATIF & 8)) {
 #define V5_R2(TT, B) row2(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, i);
+#define V5_P2(TT) rows2_pair(std::integral_constant<int, BH * PAR + TT>{}, i);
                     if (border) { V5_R2(0, true) V5_R2(1, true) V5_R2(2, true) V5_R2(3, true) V5_R2(4, true) V5_R2(5, true) V5_R2(6, true) V5_R2(7, true) V5_R2(8, true) V5_R2(9, true) }
-                    else { V5_R2(0, false) V5_R2(1, false) V5_R2(2, false) V5_R2(3, false) V5_R2(4, false) V5_R2(5, false) V5_R2(6, false) V5_R2(7, false) V5_R2(8, false) V5_R2(9, false) }
+                    else { V5_P2(0) V5_P2(2) V5_P2(4) V5_P2(6) V5_P2(8) }
                     }
 #undef V5_R2
+#undef V5_P2
                 }
                 // every storing wave drains its global accesses before the barrier behind which one lane publishes
                 // the record stored in X(i-1)
@@ -625,17 +784,23 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 V5_STAMP(3);
                 // tile 2 is free once every stage-2 wave has its rows: the a_k, b_k of this band go straight into it
                 const unsigned need = (unsigned)NS1 * (unsigned)(i + 1);
-                while (__hip_atomic_load(&s_x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(1);
+                for (unsigned spins = 0; __hip_atomic_load(&s_x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need; ++spins) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (spins > (1u << 24)) { flag_store(A.status, 1u + (unsigned)item); break; }   // (cannot happen: every wave reaches its increment)
+                    }
                 V5_STAMP(4);
                 // an interior band: every window of its a/b rows is unclipped in y
                 const bool border = BH * i - R < R + 1 || BH * i - R + BH - 1 > h - 1 - R;
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(WHATIF & 4)) {
-#define V5_R1(TT, B) row1(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, i, t1, rv);
-                if (border) { V5_R1(0, true) V5_R1(1, true) V5_R1(2, true) V5_R1(3, true) V5_R1(4, true) V5_R1(5, true) V5_R1(6, true) V5_R1(7, true) V5_R1(8, true) V5_R1(9, true) }
-                else { V5_R1(0, false) V5_R1(1, false) V5_R1(2, false) V5_R1(3, false) V5_R1(4, false) V5_R1(5, false) V5_R1(6, false) V5_R1(7, false) V5_R1(8, false) V5_R1(9, false) }
+#define V5_R1(TT, M) row1(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<int, M>{}, i, t1, rv);
+#define V5_P1(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, i, t1, rv);
+                if (border) { V5_R1(0, 2) V5_R1(1, 2) V5_R1(2, 2) V5_R1(3, 2) V5_R1(4, 2) V5_R1(5, 2) V5_R1(6, 2) V5_R1(7, 2) V5_R1(8, 2) V5_R1(9, 2) }
+                else if (xedge || k == 0) { V5_R1(0, 1) V5_R1(1, 1) V5_R1(2, 1) V5_R1(3, 1) V5_R1(4, 1) V5_R1(5, 1) V5_R1(6, 1) V5_R1(7, 1) V5_R1(8, 1) V5_R1(9, 1) }
+                else { V5_P1(0) V5_P1(2) V5_P1(4) V5_P1(6) V5_P1(8) }
                 }
 #undef V5_R1
+#undef V5_P1
             }
             have_pref = pred && (seen == FLAG_DONE || seen >= (unsigned)i + 2u);
             // ---- hand-in of record i+1 (needed by R(i+1)): prefetched at the top of X1 if it had been published
@@ -646,7 +811,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 seen = s_seen;
                 if constexpr (!ST2) fetch_rec(min(i + 1, NI - 1));
             }
-            if constexpr (!ST2) { if (pred && i + 1 < NI) hand_in(i + 1); }
+            if constexpr (!ST2) { if (pred && i + 1 < NI) hand_in(true); }
             V5_STAMP(5);
 #ifdef SMX_V5_DUMP
             if (item == SMX_V5_DUMP && i == SMX_V5_DUMP_IT && SMX_V5_DUMP_PH == 2) {
@@ -661,9 +826,164 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             band(std::integral_constant<int, 0>{}, i);
             if (i + 1 < NI) band(std::integral_constant<int, 1>{}, i + 1);
         }
+        } else {
+        // ============================= PIPE: the row scans run beside the comb rows ===============================
+        // Scan pass s (s = -1 .. NI-2) = stage-1 band s+1 and the a/b band s-1, by the scan wave during slot s; slot s also
+        // has the comb rows of stage 1 on band s (scanned in pass s-1) and of stage 2 on the a/b band s-2 (scanned in pass
+        // s-1, taken out of its tile at the start of the slot), and the cost wave's band s+2.  ONE workgroup barrier per slot.
+        // Stage-1 band b lives in tile1[b mod 3], the a/b band b in tile2s[b mod 2], the carries of pass s in
+        // cin1s[s mod 2].  The hand-off record of pass s -- {carries of band s+1, halo of the a/b band s-1} -- has index s+1.
+        auto T1 = [&](int b) { return tile1[(b + 3) % 3]; };
+        auto T2 = [&](int b) { return tile2s[(b + 2) & 1]; };
+        auto CI = [&](int sp) { return cin1s[(sp + 2) & 1]; };
+        if (pred) {
+            if (tid == 0) spin_pred(1u);
+            wg_barrier();
+            seen = s_seen;
+        }
+        have_pref = pred;
+        if constexpr (ROLE == ROLE_S1) {
+            fetch_rec(0);
+            issue_guid(0, 0);
+            if (pred) { cin1 = CI(-1); hand_in(false); }
+        }
+        if constexpr (ROLE == ROLE_COST) eval_band(0, T1(0));
+        if constexpr (ROLE == ROLE_S2 || (EVAL_S1 && ROLE == ROLE_S1)) { u4 ea, eb; eval_issue(0, ea, eb); eval_finish(0, T1(0), ea, eb); }
+        auto slot = [&](auto PARc, int sl) {
+            constexpr int PAR = decltype(PARc)::value;
+            [[maybe_unused]] const int i = sl;          // (V5_STAMP)
+            wg_barrier();
+            V5_STAMP(0);
+            V5_STAMP(1);
+            V5_STAMP(2);
+            if constexpr (ROLE >= ROLE_SCAN) { V5_STAMP(3); V5_STAMP(4); }
+            // every wave must come to the same `seen` (the wait below has a barrier in it): the peek of the previous slot, written
+            // before the barrier above and not touched during this slot; flags only grow, so a stale entry is harmless
+            seen = max(seen, s_peek[sl & 1]);
+            if constexpr (ROLE == ROLE_SCAN) {
+                if (!(WHATIF & 1024)) __builtin_amdgcn_s_setprio(3);
+                if (!(WHATIF & 1) && sl + 1 < NI) rowscans(sl + 1, sl - 1, T1(sl + 1), T2(sl - 1), CI(sl));
+                __builtin_amdgcn_s_setprio(0);
+            } else if constexpr (ROLE == ROLE_COST) {
+                if (lane == 63) {
+                    // an otherwise idle lane looks at the left neighbour's flag for the prefetch of the next record
+                    if (pred && seen != FLAG_DONE && seen < (unsigned)sl + 4u) s_peek[(sl + 1) & 1] = flag_load(myflag - 1);
+                    // ticket of the next item, one slot before the end
+                    if (sl == NI - 1)
+                        s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                if (!(WHATIF & 2) && sl + 2 < NI) eval_band(sl + 2, T1(sl + 2));
+            } else if constexpr (ROLE == ROLE_S1) {
+                // the record of pass sl+1 is needed at the end of this slot: its load goes out now (unconditionally);
+                // what it returns counts only if the record had been published
+                fetch_rec(min(sl + 2, NI - 1));
+                u4 ea = {0, 0, 0, 0}, eb = {0, 0, 0, 0};
+                const bool ev = EVAL_S1 && !(WHATIF & 2) && sl + 2 < NI;
+                if (ev) eval_issue(sl + 2, ea, eb);              // this thread's quad of the stage-1 inputs of band sl+2 ...
+                if (sl < 0 && ev) eval_finish(sl + 2, T1(sl + 2), ea, eb);
+                if (sl >= 0) {
+                    const float* const t1 = T1(sl);
+                    f2 rv = tile_rd(t1 + jt);
+                    tile2 = T2(sl);
+                    V5_STAMP(3);
+                    // tile 2 of this band's parity is free once every stage-2 wave has taken the a/b band sl-2 out of it
+                    const unsigned need = (unsigned)NS1 * (unsigned)(sl + 1);
+                    for (unsigned spins = 0; __hip_atomic_load(&s_x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need; ++spins) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (spins > (1u << 24)) { flag_store(A.status, 1u + (unsigned)item); break; }   // (cannot happen: every wave reaches its increment)
+                    }
+                    V5_STAMP(4);
+                    const bool border = BH * sl - R < R + 1 || BH * sl - R + BH - 1 > h - 1 - R;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(WHATIF & 4)) {
+#define V5_R1(TT, M) row1(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<int, M>{}, sl, t1, rv);
+#define V5_P1(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, sl, t1, rv);
+                    if (border) { V5_R1(0, 2) V5_R1(1, 2) V5_R1(2, 2) V5_R1(3, 2) V5_R1(4, 2) V5_R1(5, 2) V5_R1(6, 2) V5_R1(7, 2) V5_R1(8, 2) V5_R1(9, 2) }
+                    else if (xedge || k == 0) { V5_R1(0, 1) V5_R1(1, 1) V5_R1(2, 1) V5_R1(3, 1) V5_R1(4, 1) V5_R1(5, 1) V5_R1(6, 1) V5_R1(7, 1) V5_R1(8, 1) V5_R1(9, 1) }
+                    else { V5_P1(0) V5_P1(2) V5_P1(4) V5_P1(6) V5_P1(8) }
+                    }
+#undef V5_R1
+#undef V5_P1
+                    if (ev) eval_finish(sl + 2, T1(sl + 2), ea, eb);   // ... evaluated behind the comb rows
+                    issue_guid(sl + 1, 0);
+                }
+            } else {
+                u4 ea = {0, 0, 0, 0}, eb = {0, 0, 0, 0};
+                const bool ev = !(WHATIF & 2) && sl + 2 < NI;
+                if (sl < 0 && ev) { eval_issue(sl + 2, ea, eb); eval_finish(sl + 2, T1(sl + 2), ea, eb); }
+                if (sl >= 0) {
+                    if (succ && tid == 64 * 2 * NS1 - 1 && sl >= 1) flag_store(myflag, (unsigned)sl);
+                    // the a/b band sl-2 (scanned in pass sl-1) out of its tile; the record of pass sl-1 (index sl): halo of that
+                    // band, carries of stage-1 band sl
+                    const float* const t2 = T2(sl);
+#pragma unroll
+                    for (int t = 0; t < BH; ++t) r2[t] = tile_rd(t2 + t * RS + jt);
+                    const int hq = hu_idx();
+                    if (succ && hq >= 0 && hq < REC_U) {
+                        f4 hov;
+                        if (hq < NHU) {
+                            const int t = hq / 10, j = (hq - 10 * t) * 2;
+                            const float* p = t2 + t * RS + OWS + j;
+                            hov = (f4){p[0], p[P1], p[1], p[P1 + 1]};
+                        } else {
+                            const float* p = T1(sl) + 2 * (hq - NHU) * RS + OWS - 1;
+                            hov = (f4){p[0], p[P1], p[RS], p[RS + P1]};
+                        }
+                        st16_sc1(r_hand, (unsigned)(o_out + sl * REC_U * 16) + (unsigned)hq * 16u, hov);
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r2[0]), "+v"(r2[1]), "+v"(r2[2]), "+v"(r2[3]), "+v"(r2[4]), "+v"(r2[5]),
+                                 "+v"(r2[6]), "+v"(r2[7]), "+v"(r2[8]), "+v"(r2[9]) :: "memory");
+                    if (lane == 0) __hip_atomic_fetch_add(&s_x1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    V5_STAMP(3);
+                    V5_STAMP(4);
+                    if (ev) eval_issue(sl + 2, ea, eb);          // this thread's quad of the stage-1 inputs of band sl+2 ...
+                    if (sl >= 2) {
+                        const int yq0 = BH * (sl - 2) - 2 * R;
+                        const bool border = yq0 < R + 1 || yq0 + BH - 1 > h - 1 - R;
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!(WHATIF & 8)) {
+#define V5_R2(TT, B) row2(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, sl);
+#define V5_P2(TT) rows2_pair(std::integral_constant<int, BH * PAR + TT>{}, sl);
+                        if (border) { V5_R2(0, true) V5_R2(1, true) V5_R2(2, true) V5_R2(3, true) V5_R2(4, true) V5_R2(5, true) V5_R2(6, true) V5_R2(7, true) V5_R2(8, true) V5_R2(9, true) }
+                        else { V5_P2(0) V5_P2(2) V5_P2(4) V5_P2(6) V5_P2(8) }
+                        }
+#undef V5_R2
+#undef V5_P2
+                    }
+                    if (ev) eval_finish(sl + 2, T1(sl + 2), ea, eb);   // ... evaluated behind the comb rows
+                    issue_guid(sl, BH * (sl - 1) - 2 * R);
+                    // the record stored above is complete in memory before the barrier behind which it is published
+                    drain_vmem();
+                }
+            }
+            // ---- hand-in of the record of pass sl+1 (index sl+2), prefetched at the top of the slot if it had been published
+            have_pref = pred && (seen == FLAG_DONE || seen >= (unsigned)sl + 3u);
+            if (pred && !have_pref && sl + 2 < NI) {
+                if (tid == 0) spin_pred((unsigned)sl + 3u);
+                wg_barrier();
+                seen = s_seen;
+                if constexpr (ROLE == ROLE_S1) fetch_rec(min(sl + 2, NI - 1));
+            }
+            if constexpr (ROLE == ROLE_S1) {
+                // (the halo is that of the a/b band sl, which the comb rows above have just written into the same tile)
+                if (pred && sl + 2 < NI) { cin1 = CI(sl + 1); tile2 = T2(sl); hand_in(sl >= 0); }
+            }
+            V5_STAMP(5);
         };
-        if (tid == 0) s_x1 = 0u;        // (ordered before the first use by the barrier at the top of the first band)
-        if (st2w) item_body(std::true_type{}); else item_body(std::false_type{});
+        slot(std::integral_constant<int, 1>{}, -1);
+        for (int sl = 0; sl < NI; sl += 2) {
+            slot(std::integral_constant<int, 0>{}, sl);
+            if (sl + 1 < NI) slot(std::integral_constant<int, 1>{}, sl + 1);
+        }
+        }
+        };
+        if (tid == 0) { s_x1 = 0u; s_peek[0] = 0u; s_peek[1] = 0u; }   // (ordered before the first use by the barrier at the top of the first band)
+        if (wave < NS1) item_body(std::integral_constant<int, ROLE_S1>{});
+        else if (wave < 2 * NS1) item_body(std::integral_constant<int, ROLE_S2>{});
+        else if constexpr (PIPE) {
+            if (wave == 2 * NS1) item_body(std::integral_constant<int, ROLE_SCAN>{});
+            else item_body(std::integral_constant<int, ROLE_COST>{});
+        }
         // the last record and the last q rows: drained, then published
         drain_vmem();
         wg_barrier();

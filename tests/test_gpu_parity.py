@@ -352,7 +352,7 @@ def _ragged_shapes(OW, BH, dense):
 
 # literal copies of the library constants; test_ragged_shapes_match_the_library_geometry pins them
 _RING = (64, 16)       # smx_agg_v4.hip: output columns per strip, rows per band
-_COMB = (209, 10)      # smx_agg_v5.hip (comb length 12)
+_COMB = (152, 10)      # smx_agg_v5.hip (comb length 9)
 
 
 def test_ragged_shapes_match_the_library_geometry():
@@ -369,7 +369,7 @@ def test_ragged_shapes_match_the_library_geometry():
                          [(5,) + s for s in _ragged_shapes(*_COMB, False)])
 def test_fused_path_small_and_ragged(orc, path, w, h, D):
     """Strip / band boundaries of both fused walkers (ring walker: 64 output columns per strip, 16-row bands,
-    36-row rings; comb walker: 209 columns, 10-row bands, 20-slot register rings -- the shapes follow
+    36-row rings; comb walker: 152 columns, 10-row bands, 20-slot register rings -- the shapes follow
     smx_agg_geometry), images smaller than one tile, disparity ranges wider than the image."""
     rng = np.random.default_rng(w * 7 + h * 3 + D)
     base = rng.integers(0, 256, size=(h, w + D), dtype=np.uint8)
