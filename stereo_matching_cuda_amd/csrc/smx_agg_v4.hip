@@ -1541,6 +1541,12 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             b.nslices = a.nslices; b.nsv = a.nsv; b.nitems = a.nitems;
             b.hand = (float*)hand; b.flags = a.flags; b.ticket = a.ticket; b.status = a.status;
             b.cc = a.cc;
+            {
+                const _Float16 hc = (_Float16)a.cc.th_color, hg = (_Float16)a.cc.th_grad;
+                unsigned short uc, ug;
+                memcpy(&uc, &hc, 2); memcpy(&ug, &hg, 2);
+                b.th2 = (unsigned)uc | ((unsigned)ug << 16);
+            }
             b.qperm = own_q ? 1 : 0;
             b.q_plane = qplane;
             rc = v5_launch(b, st);

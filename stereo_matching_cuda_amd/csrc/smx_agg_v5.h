@@ -45,6 +45,7 @@ struct Args {
     unsigned* ticket;     // work-item counter              (zeroed before every launch)
     unsigned* status;     // != 0: a flag wait timed out (results invalid)
     CostConst cc;
+    unsigned th2;        // (th_color, th_grad) as packed halves (exact: v5_supported)
 };
 
 inline int strips(int w) { return (w + OWS - 1) / OWS; }

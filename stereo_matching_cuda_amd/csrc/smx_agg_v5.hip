@@ -97,13 +97,9 @@ __device__ unsigned long long g_stamps[10 * STAMP_SLOTS];
 #define SMX_V5_WHATIF 0
 #endif
 constexpr int WHATIF = SMX_V5_WHATIF;
-#ifndef SMX_V5_EVAL_S1
-#define SMX_V5_EVAL_S1 0
-#endif
 #ifndef SMX_V5_WMAP
 #define SMX_V5_WMAP 0
 #endif
-constexpr bool EVAL_S1 = SMX_V5_EVAL_S1;
 constexpr int WMAP = SMX_V5_WMAP;
 
 #ifdef SMX_V5_DUMP
@@ -172,6 +168,36 @@ __device__ __forceinline__ f2 div_ca_e(f2 q, f2 x, f2 ca) {
 }
 __device__ __forceinline__ f2 div_ca_m(f2 e, f2 q, f2 ca) { f2 m; asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(m) : "v"(e), "v"(ca), "v"(q)); return m; }
 
+// ---- matching cost of a cell in packed halves (cost wave of the pipelined form).  q = (pixel value, x-derivative) as two
+// halves: pixel values are the integers 0 .. 255 and derivatives multiples of 0.5 in [-127.5, 127.5] (k_v4_prep), so the
+// difference of two cells is EXACT in fp16 and min(|d|, threshold) -- thresholds exact in fp16: v5_supported -- is the very
+// number the reference's f32 arithmetic gets (costVolume.cu:187).  Against the sentinel 60000 of a partner outside the image
+// the difference rounds but stays finite and far above either threshold.  v_fma_mix_f32 with a +0 addend is the
+// correctly rounded product of a half and a float (no product here is negative), so the two weighted terms, their sum
+// and I * p round exactly where the reference's do.
+__device__ __forceinline__ unsigned cost_trunc_h2(unsigned q1, unsigned q2, unsigned th2) {
+    unsigned d;
+    asm("v_pk_add_f16 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(q1), "v"(q2));
+    d &= 0x7fff7fffu;
+    asm("v_pk_min_f16 %0, %1, %2" : "=v"(d) : "v"(d), "s"(th2));
+    return d;
+}
+__device__ __forceinline__ float mix_mul_lo(unsigned h2, float s) {   // RN((float)low half * s)
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "s"(s));
+    return r;
+}
+__device__ __forceinline__ float mix_mul_hi(unsigned h2, float s) {   // RN((float)high half * s)
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "s"(s));
+    return r;
+}
+__device__ __forceinline__ float mix_mul_lo_v(unsigned h2, float v) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(v));
+    return r;
+}
+
 // a cell's (first, second) component of a tile row (the compiler forms ds_read2st64_b32 / ds_write2st64_b32:
 // the planes are 5 x 64 dwords apart)
 __device__ __forceinline__ f2 tile_rd(const float* p) { return (f2){p[0], p[P1]}; }
@@ -191,7 +217,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     const int lane = threadIdx.x & 63;
     const int hwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // role of a hardware wave (waves w and w + 4 of a workgroup share a SIMD)
-    const int wave = PIPE && WMAP == 1 ? (int)((0x75436210u >> (4 * hwave)) & 7u) : hwave;
+    const int wave = PIPE && WMAP == 1 ? (int)((0x75436210u >> (4 * hwave)) & 7u) : PIPE && WMAP == 2 ? (int)((0x54317620u >> (4 * hwave)) & 7u) : hwave;
     const int tid = 64 * wave + lane;
     const int w = A.w, h = A.h, K = A.K, NI = A.NI, nsv = A.nsv;
     const CostConst cc = A.cc;
@@ -217,8 +243,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     constexpr int NQROW = SW / 4;                                   // quads per tile row (76 / 57)
     constexpr int NCT = PIPE ? 64 : 64 * (NS1 - 1);                 // cost threads (PIPE: the cost wave)
     constexpr int NRB = 4;                                          // rounds whose loads are in flight together
-    // PIPE: the comb waves of both stages take one quad per thread (quads 0 .. NCT2-1: stage 2 first), the cost wave the rest
-    constexpr int NCT2 = PIPE ? (EVAL_S1 ? 2 : 1) * 64 * NS1 : 0;
+    constexpr int NCT2 = 0;
     constexpr int NQT = BH * NQROW;                                 // quads per band
     constexpr int NRQ = (NQT - NCT2 + NCT - 1) / NCT;               // rounds
 
@@ -311,8 +336,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // tile (row, column) of this thread's quad of round r; re-derived from the thread index where it is used (a few
         // integer instructions) instead of living in registers through the comb rows
         auto cost_unit = [&](int r, int& row, int& col, bool& on) {
-            const int u = PIPE && ROLE == ROLE_S2 ? opaque(tid) - 64 * NS1 : PIPE && ROLE == ROLE_S1 ? 64 * NS1 + opaque(tid)
-                          : NCT2 + r * NCT + (PIPE ? opaque(lane) : opaque(tid) - 64);
+            const int u = NCT2 + r * NCT + (PIPE ? opaque(lane) : opaque(tid) - 64);
             on = u < NQT;
             const int uc = min(u, NQT - 1);
             row = uc / NQROW;
@@ -321,6 +345,89 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // Loads of the stage-1 inputs of band ib (rows clamped into the image: every load is issued) and their evaluation
         // raw -> (p, I p) -> tile 1 buffer `dst`; cells outside the image are -0.  One phase: no register carries the raw
         // values on.  The loads of NRB rounds are in flight together.
+        // Pipelined form: the cost wave evaluates the whole band, NRQ quads per lane.  Per quad, fixed for the item: byte
+        // offsets of its four cells in the two image planes (row term included; the band term is the scalar offset of the
+        // load), byte offset in a tile, the row term alone and which of the four columns lie in the image (edge items).
+        constexpr int CWN = (PIPE && ROLE == ROLE_COST) ? NRQ : 1;
+        unsigned cw_a1[CWN], cw_a2[CWN], cw_t[CWN], cw_rowb[CWN], cw_m[CWN];
+        if constexpr (PIPE && ROLE == ROLE_COST) {
+#pragma unroll
+            for (int r = 0; r < NRQ; ++r) {
+                int row, col; bool on;
+                cost_unit(r, row, col, on);
+                const unsigned rowb = (unsigned)row * fgw4;
+                cw_rowb[r] = (unsigned)opaque((int)rowb);       // (opaque: computed here, once per item, not where the band loop uses them)
+                cw_a1[r] = (unsigned)opaque((int)((unsigned)(min(max(base1 + col, -PADX), w) + PADX) * 4u + rowb));
+                cw_a2[r] = (unsigned)opaque((int)((unsigned)(min(max(base1 + col + d, -PADX), w) + PADX) * 4u + rowb));
+                cw_t[r] = (unsigned)opaque((int)(on ? (unsigned)(row * RS + col) * 4u : (unsigned)SW * 4u));      // (lanes without a quad: a padding column)
+                unsigned m = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m |= (base1 + col + j >= 0 && base1 + col + j < w) ? 1u << j : 0u;
+                cw_m[r] = (unsigned)opaque((int)m);
+            }
+        }
+        // (loading a band ahead of its slot -- 56 registers through the slot -- spills and is slower: measured)
+        u4 cw_ra[CWN], cw_rb[CWN];
+        auto cw_issue = [&](int ib, auto R0c) {
+            constexpr int R0 = decltype(R0c)::value, R1 = R0 + NRB < CWN ? R0 + NRB : CWN;
+            const unsigned bandb = (unsigned)(BH * ib) * fgw4, ymaxb = (unsigned)(h - 1) * fgw4;
+            if (BH * ib + BH <= h) {
+#pragma unroll
+                for (int r = R0; r < R1; ++r) {
+                    cw_ra[r] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a1[r], o_fg1 + (int)bandb, 0);
+                    cw_rb[r] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a2[r], o_fg2 + (int)bandb, 0);
+                }
+            } else {
+                // rows behind the image read the last image row (every load is issued; their cells become -0 in cw_finish)
+#pragma unroll
+                for (int r = R0; r < R1; ++r) {
+                    const int yadj = min((int)bandb, (int)ymaxb - (int)cw_rowb[r]);
+                    cw_ra[r] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a1[r] + yadj, o_fg1, 0);
+                    cw_rb[r] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a2[r] + yadj, o_fg2, 0);
+                }
+            }
+        };
+        auto cw_finish = [&](int ib, float* dst, auto R0c, auto EDGEc) {
+            constexpr bool EDGE = decltype(EDGEc)::value;
+            constexpr int R0 = decltype(R0c)::value, R1 = R0 + NRB < CWN ? R0 + NRB : CWN;
+            const unsigned bandb = (unsigned)(BH * ib) * fgw4, ymaxb = (unsigned)(h - 1) * fgw4;
+            char* const dstb = (char*)dst;
+#pragma unroll
+            for (int r = R0; r < R1; ++r) {
+                const unsigned q1[4] = {cw_ra[r].x, cw_ra[r].y, cw_ra[r].z, cw_ra[r].w}, q2[4] = {cw_rb[r].x, cw_rb[r].y, cw_rb[r].z, cw_rb[r].w};
+                f4 t1, t2, ip;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const unsigned m = cost_trunc_h2(q1[j], q2[j], A.th2);
+                    t1[j] = mix_mul_lo(m, cc.oma);
+                    t2[j] = mix_mul_hi(m, cc.alpha);
+                }
+                f4 pp = t1 + t2;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ip[j] = mix_mul_lo_v(q1[j], pp[j]);
+                if constexpr (EDGE) {
+                    const bool rowok = bandb + cw_rowb[r] <= ymaxb;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (!(rowok && ((cw_m[r] >> j) & 1u))) { pp[j] = -0.0f; ip[j] = -0.0f; }
+                }
+                *(f4*)(dstb + cw_t[r]) = pp;
+                *(f4*)(dstb + cw_t[r] + P1 * 4) = ip;
+            }
+        };
+        auto eval_band_p = [&](int ib, float* dst) {
+            static_assert(2 * NRB >= CWN, "two batches");
+            auto run = [&](auto EDGEc) {
+                cw_issue(ib, std::integral_constant<int, 0>{});
+                cw_finish(ib, dst, std::integral_constant<int, 0>{}, EDGEc);
+                if constexpr (NRB < CWN) {
+                    cw_issue(ib, std::integral_constant<int, NRB>{});
+                    cw_finish(ib, dst, std::integral_constant<int, NRB>{}, EDGEc);
+                }
+            };
+            // (two versions of the whole band: the interior one has no trace of the edge handling)
+            if (xedge || BH * ib + BH > h) run(std::true_type{}); else run(std::false_type{});
+        };
         auto eval_band = [&](int ib, float* dst) {
             auto off = [&](int row, int col, int dd) {
                 const int y = min(BH * ib + row, h - 1);
@@ -365,36 +472,6 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                         }
                     }
                 }
-            }
-        };
-        // PIPE, comb roles: this thread's one quad of band ib -- loads at the start of the slot, evaluation behind the comb rows
-        auto eval_issue = [&](int ib, u4& ra, u4& rb) {
-            int row, col; bool on;
-            cost_unit(0, row, col, on);
-            const int y = min(BH * ib + row, h - 1);
-            auto off = [&](int dd) { return (unsigned)(min(max(base1 + col + dd, -PADX), w) + PADX) * 4u + (unsigned)y * fgw4; };
-            ra = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(0), o_fg1, 0);
-            rb = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(d), o_fg2, 0);
-        };
-        auto eval_finish = [&](int ib, float* dst, u4 ra, u4 rb) {
-            int row, col; bool on;
-            cost_unit(0, row, col, on);
-            const bool edge = xedge || BH * ib + BH > h;
-            const unsigned r1[4] = {ra.x, ra.y, ra.z, ra.w}, r2q[4] = {rb.x, rb.y, rb.z, rb.w};
-            float* p = dst + row * RS + col;
-#pragma unroll
-            for (int jj = 0; jj < 4; jj += 2) {
-                f2 v[2];
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    v[j] = cost_pair_s(__builtin_bit_cast(fg_t, r1[jj + j]), __builtin_bit_cast(fg_t, r2q[jj + j]), cc);
-                    if (edge) {
-                        const int ci = base1 + col + jj + j;
-                        if (!(ci >= 0 && ci < w && BH * ib + row < h)) v[j] = NZ2;
-                    }
-                }
-                *(f2*)(p + jj) = (f2){v[0].x, v[1].x};
-                *(f2*)(p + P1 + jj) = (f2){v[0].y, v[1].y};
             }
         };
         // guidance of the output rows of iteration ib (rows clamped into the image: every load is issued)
@@ -444,8 +521,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // stage 1: band i1 in tile t1p; stage 2: the a/b band i2 (rows 10 i2 - 9 ..) in tile t2p
         auto rowscans = [&](int i1, int i2, float* t1p, float* t2p, float (*cinp)[2]) {
             const int sc_l = lane & 31, sc_st = lane >> 5, sc_row = sc_l % BH, sc_comp = sc_l / BH;
+            const bool sc_on = sc_l < 2 * BH;
             const int y = sc_st == 0 ? BH * i1 + sc_row : BH * i2 - R + sc_row;
-            const bool act = sc_l < 2 * BH && y >= 0 && y < h && (sc_st == 0 ? i1 >= 0 : i2 >= 0);
+            const bool act = sc_on && y >= 0 && y < h && (sc_st == 0 ? i1 >= 0 : i2 >= 0);
             if (!act) return;
             float* const row = (sc_st == 0 ? t1p : t2p) + sc_row * RS + sc_comp * P1;
             // stage 1 starts from the left neighbour's running row sum (or -0); stage 2 of a strip with a left
@@ -575,8 +653,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // Two comb rows of stage 1 at once, interior band of an interior strip (MODE 0 of row1): the two dependent chains
         // interleaved by hand, so that neither the wait states behind a packed operation nor the s_nop in front of a DPP
         // read stay empty.  N0 = ring slot of the first row (even).
-        auto rows1_pair = [&](auto N0c, int i, const float* t1, f2& rv) {
+        auto rows1_pair = [&](auto N0c, auto EDGEc, int i, const float* t1, f2& rv) {
             constexpr int N0 = decltype(N0c)::value, T0 = N0 % BH;
+            constexpr bool EDGE = decltype(EDGEc)::value;   // strip 0 or one with columns outside the image (interior band)
             constexpr int SLa = N0, SLb = N0 + 1, SLPa = (N0 + RD - 1) % RD, S01a = (N0 + 1) % RD, S01b = (N0 + 2) % RD;
             const f2 rvb = tile_rd(t1 + (T0 + 1) * RS + jt);
             const f2 rvn = tile_rd(t1 + (T0 + 2 < BH ? T0 + 2 : T0 + 1) * RS + jt);
@@ -589,8 +668,18 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             ua = box_top(ua, old_a);
             ring[SLb] = sb;
             ub = ub - ring[S01b];
+            if constexpr (EDGE && L != 16) {
+                // (no zero fill in front of a comb that is not a whole DPP row: the first lane of a comb of strip 0 -- its a/b
+                // columns 0 .. 8 are outputs -- takes the box without left taps)
+                const f2 u0a = ring[SLa] - old_a;
+                if (il0 && k == 0) ua = u0a;
+            }
             const f2 qa = div_ca_q(ua, ca_i);
             ub = box_top(ub, ring[S01b]);
+            if constexpr (EDGE && L != 16) {
+                const f2 u0b = sb - ring[S01b];
+                if (il0 && k == 0) ub = u0b;
+            }
             const f2 ea = div_ca_e(qa, ua, ca_i);
             const f2 qb = div_ca_q(ub, ca_i);
             const f2 ma = div_ca_m(ea, qa, ca_i);      // (mean_p, mean_Ip)
@@ -606,9 +695,13 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             const float akb = 1.0f * tb * gb.y;
             const float bka = 1.0f * ma.x - mb2a;
             const float mb2b = 1.0f * gb.x * akb;
-            tile_wr(tile2 + T0 * RS + jw, (f2){aka, bka});
+            f2 aba = {aka, bka};
+            if (EDGE && !col_ok) aba = NZ2;            // a/b columns outside the image: -0
+            tile_wr(tile2 + T0 * RS + jw, aba);
             const float bkb = 1.0f * mb.x - mb2b;
-            tile_wr(tile2 + (T0 + 1) * RS + jw, (f2){akb, bkb});
+            f2 abb = {akb, bkb};
+            if (EDGE && !col_ok) abb = NZ2;
+            tile_wr(tile2 + (T0 + 1) * RS + jw, abb);
             rv = rvn;
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -794,7 +887,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(WHATIF & 4)) {
 #define V5_R1(TT, M) row1(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<int, M>{}, i, t1, rv);
-#define V5_P1(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, i, t1, rv);
+#define V5_P1(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::false_type{}, i, t1, rv);
                 if (border) { V5_R1(0, 2) V5_R1(1, 2) V5_R1(2, 2) V5_R1(3, 2) V5_R1(4, 2) V5_R1(5, 2) V5_R1(6, 2) V5_R1(7, 2) V5_R1(8, 2) V5_R1(9, 2) }
                 else if (xedge || k == 0) { V5_R1(0, 1) V5_R1(1, 1) V5_R1(2, 1) V5_R1(3, 1) V5_R1(4, 1) V5_R1(5, 1) V5_R1(6, 1) V5_R1(7, 1) V5_R1(8, 1) V5_R1(9, 1) }
                 else { V5_P1(0) V5_P1(2) V5_P1(4) V5_P1(6) V5_P1(8) }
@@ -847,8 +940,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             issue_guid(0, 0);
             if (pred) { cin1 = CI(-1); hand_in(false); }
         }
-        if constexpr (ROLE == ROLE_COST) eval_band(0, T1(0));
-        if constexpr (ROLE == ROLE_S2 || (EVAL_S1 && ROLE == ROLE_S1)) { u4 ea, eb; eval_issue(0, ea, eb); eval_finish(0, T1(0), ea, eb); }
+        if constexpr (ROLE == ROLE_COST) eval_band_p(0, T1(0));
         auto slot = [&](auto PARc, int sl) {
             constexpr int PAR = decltype(PARc)::value;
             [[maybe_unused]] const int i = sl;          // (V5_STAMP)
@@ -872,15 +964,11 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     if (sl == NI - 1)
                         s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                if (!(WHATIF & 2) && sl + 2 < NI) eval_band(sl + 2, T1(sl + 2));
+                if (!(WHATIF & 2) && sl + 2 < NI) eval_band_p(sl + 2, T1(sl + 2));
             } else if constexpr (ROLE == ROLE_S1) {
                 // the record of pass sl+1 is needed at the end of this slot: its load goes out now (unconditionally);
                 // what it returns counts only if the record had been published
                 fetch_rec(min(sl + 2, NI - 1));
-                u4 ea = {0, 0, 0, 0}, eb = {0, 0, 0, 0};
-                const bool ev = EVAL_S1 && !(WHATIF & 2) && sl + 2 < NI;
-                if (ev) eval_issue(sl + 2, ea, eb);              // this thread's quad of the stage-1 inputs of band sl+2 ...
-                if (sl < 0 && ev) eval_finish(sl + 2, T1(sl + 2), ea, eb);
                 if (sl >= 0) {
                     const float* const t1 = T1(sl);
                     f2 rv = tile_rd(t1 + jt);
@@ -897,20 +985,18 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(WHATIF & 4)) {
 #define V5_R1(TT, M) row1(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<int, M>{}, sl, t1, rv);
-#define V5_P1(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, sl, t1, rv);
+#define V5_P1(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::false_type{}, sl, t1, rv);
+#define V5_P1E(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::true_type{}, sl, t1, rv);
                     if (border) { V5_R1(0, 2) V5_R1(1, 2) V5_R1(2, 2) V5_R1(3, 2) V5_R1(4, 2) V5_R1(5, 2) V5_R1(6, 2) V5_R1(7, 2) V5_R1(8, 2) V5_R1(9, 2) }
-                    else if (xedge || k == 0) { V5_R1(0, 1) V5_R1(1, 1) V5_R1(2, 1) V5_R1(3, 1) V5_R1(4, 1) V5_R1(5, 1) V5_R1(6, 1) V5_R1(7, 1) V5_R1(8, 1) V5_R1(9, 1) }
+                    else if (xedge || k == 0) { V5_P1E(0) V5_P1E(2) V5_P1E(4) V5_P1E(6) V5_P1E(8) }
                     else { V5_P1(0) V5_P1(2) V5_P1(4) V5_P1(6) V5_P1(8) }
                     }
 #undef V5_R1
 #undef V5_P1
-                    if (ev) eval_finish(sl + 2, T1(sl + 2), ea, eb);   // ... evaluated behind the comb rows
+#undef V5_P1E
                     issue_guid(sl + 1, 0);
                 }
             } else {
-                u4 ea = {0, 0, 0, 0}, eb = {0, 0, 0, 0};
-                const bool ev = !(WHATIF & 2) && sl + 2 < NI;
-                if (sl < 0 && ev) { eval_issue(sl + 2, ea, eb); eval_finish(sl + 2, T1(sl + 2), ea, eb); }
                 if (sl >= 0) {
                     if (succ && tid == 64 * 2 * NS1 - 1 && sl >= 1) flag_store(myflag, (unsigned)sl);
                     // the a/b band sl-2 (scanned in pass sl-1) out of its tile; the record of pass sl-1 (index sl): halo of that
@@ -936,7 +1022,6 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     if (lane == 0) __hip_atomic_fetch_add(&s_x1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     V5_STAMP(3);
                     V5_STAMP(4);
-                    if (ev) eval_issue(sl + 2, ea, eb);          // this thread's quad of the stage-1 inputs of band sl+2 ...
                     if (sl >= 2) {
                         const int yq0 = BH * (sl - 2) - 2 * R;
                         const bool border = yq0 < R + 1 || yq0 + BH - 1 > h - 1 - R;
@@ -950,7 +1035,6 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
 #undef V5_R2
 #undef V5_P2
                     }
-                    if (ev) eval_finish(sl + 2, T1(sl + 2), ea, eb);   // ... evaluated behind the comb rows
                     issue_guid(sl, BH * (sl - 1) - 2 * R);
                     // the record stored above is complete in memory before the barrier behind which it is published
                     drain_vmem();
@@ -1125,7 +1209,11 @@ bool v5_supported(const smx_params* p) {
     const float m1 = c.th_color < 1.0f ? c.th_color : 1.0f, m2 = c.th_grad < 0.5f ? c.th_grad : 0.5f;
     const float t1 = c.oma * m1, t2 = c.alpha * m2;
     auto ok = [](float t) { return t == 0.0f || t >= 0x1p-60f; };
-    return ok(t1) && ok(t2);
+    if (!(ok(t1) && ok(t2))) return false;
+    // the pipelined form truncates in packed halves: thresholds exact (and finite) in fp16
+    if (v5::PIPE && !((float)(_Float16)c.th_color == c.th_color && (float)(_Float16)c.th_grad == c.th_grad && c.th_color < 60000.0f && c.th_grad < 60000.0f))
+        return false;
+    return true;
 }
 
 int v5_launch(const v5::Args& a, hipStream_t st) {
