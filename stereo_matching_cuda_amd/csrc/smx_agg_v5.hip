@@ -653,7 +653,17 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // Two comb rows of stage 1 at once, interior band of an interior strip (MODE 0 of row1): the two dependent chains
         // interleaved by hand, so that neither the wait states behind a packed operation nor the s_nop in front of a DPP
         // read stay empty.  N0 = ring slot of the first row (even).
-        auto rows1_pair = [&](auto N0c, auto EDGEc, int i, const float* t1, f2& rv) {
+        // PIPE, stage-1 role: tile 2 of a band's parity is free once every stage-2 wave has taken the a/b band two bands back out
+        // of it (they do that first thing in the slot and count up s_x1); waited for right in front of the first a/b store
+        unsigned x1_need = 0;
+        auto wait_x1 = [&]() {
+            for (unsigned spins = 0; __hip_atomic_load(&s_x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < x1_need; ++spins) {
+                __builtin_amdgcn_s_sleep(1);
+                if (spins > (1u << 24)) { flag_store(A.status, 1u + (unsigned)item); break; }   // (cannot happen: every wave reaches its increment)
+            }
+            asm volatile("" ::: "memory");
+        };
+        auto rows1_pair = [&](auto N0c, auto EDGEc, auto WAITc, int i, const float* t1, f2& rv) {
             constexpr int N0 = decltype(N0c)::value, T0 = N0 % BH;
             constexpr bool EDGE = decltype(EDGEc)::value;   // strip 0 or one with columns outside the image (interior band)
             constexpr int SLa = N0, SLb = N0 + 1, SLPa = (N0 + RD - 1) % RD, S01a = (N0 + 1) % RD, S01b = (N0 + 2) % RD;
@@ -697,6 +707,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             const float mb2b = 1.0f * gb.x * akb;
             f2 aba = {aka, bka};
             if (EDGE && !col_ok) aba = NZ2;            // a/b columns outside the image: -0
+            if constexpr (decltype(WAITc)::value) wait_x1();
             tile_wr(tile2 + T0 * RS + jw, aba);
             const float bkb = 1.0f * mb.x - mb2b;
             f2 abb = {akb, bkb};
@@ -887,7 +898,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(WHATIF & 4)) {
 #define V5_R1(TT, M) row1(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<int, M>{}, i, t1, rv);
-#define V5_P1(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::false_type{}, i, t1, rv);
+#define V5_P1(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::false_type{}, std::false_type{}, i, t1, rv);
                 if (border) { V5_R1(0, 2) V5_R1(1, 2) V5_R1(2, 2) V5_R1(3, 2) V5_R1(4, 2) V5_R1(5, 2) V5_R1(6, 2) V5_R1(7, 2) V5_R1(8, 2) V5_R1(9, 2) }
                 else if (xedge || k == 0) { V5_R1(0, 1) V5_R1(1, 1) V5_R1(2, 1) V5_R1(3, 1) V5_R1(4, 1) V5_R1(5, 1) V5_R1(6, 1) V5_R1(7, 1) V5_R1(8, 1) V5_R1(9, 1) }
                 else { V5_P1(0) V5_P1(2) V5_P1(4) V5_P1(6) V5_P1(8) }
@@ -974,19 +985,15 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     f2 rv = tile_rd(t1 + jt);
                     tile2 = T2(sl);
                     V5_STAMP(3);
-                    // tile 2 of this band's parity is free once every stage-2 wave has taken the a/b band sl-2 out of it
-                    const unsigned need = (unsigned)NS1 * (unsigned)(sl + 1);
-                    for (unsigned spins = 0; __hip_atomic_load(&s_x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need; ++spins) {
-                        __builtin_amdgcn_s_sleep(1);
-                        if (spins > (1u << 24)) { flag_store(A.status, 1u + (unsigned)item); break; }   // (cannot happen: every wave reaches its increment)
-                    }
-                    V5_STAMP(4);
+                    x1_need = (unsigned)NS1 * (unsigned)(sl + 1);
                     const bool border = BH * sl - R < R + 1 || BH * sl - R + BH - 1 > h - 1 - R;
+                    if (border || (WHATIF & 4)) wait_x1();      // (the interior rows wait in front of their first store)
+                    V5_STAMP(4);
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(WHATIF & 4)) {
 #define V5_R1(TT, M) row1(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<int, M>{}, sl, t1, rv);
-#define V5_P1(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::false_type{}, sl, t1, rv);
-#define V5_P1E(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::true_type{}, sl, t1, rv);
+#define V5_P1(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::false_type{}, std::integral_constant<bool, TT == 0>{}, sl, t1, rv);
+#define V5_P1E(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::true_type{}, std::integral_constant<bool, TT == 0>{}, sl, t1, rv);
                     if (border) { V5_R1(0, 2) V5_R1(1, 2) V5_R1(2, 2) V5_R1(3, 2) V5_R1(4, 2) V5_R1(5, 2) V5_R1(6, 2) V5_R1(7, 2) V5_R1(8, 2) V5_R1(9, 2) }
                     else if (xedge || k == 0) { V5_P1E(0) V5_P1E(2) V5_P1E(4) V5_P1E(6) V5_P1E(8) }
                     else { V5_P1(0) V5_P1(2) V5_P1(4) V5_P1(6) V5_P1(8) }
