@@ -133,6 +133,20 @@ int smx_create(const smx_params* p, int w, int h, int size_d, smx_ctx** ctx);
 int smx_ctx_stereo_pair(smx_ctx* ctx, const uint8_t* gray_l, const uint8_t* gray_r, int dminl, int dminr,
                         const smx_pair_out* out);
 int smx_destroy(smx_ctx* ctx);
+/* Pipelined host-pointer entry: uploads of pair k+1 and downloads of pair k-1 run under the aggregation of pair k
+ * (three streams, pinned staging buffers owned by the context; it replaces the synchronous per-slice upload / compute /
+ * download churn of guidedFilter.cu:50-56,182-194,244-248).
+ *   smx_ctx_stereo_pair_async  copies the two images into pinned staging (the caller's buffers are free when it returns),
+ *                              enqueues upload -> path -> download of the eight result planes and returns without
+ *                              waiting.  At most two pairs may be in flight (SMX_E_ARG otherwise).
+ *   smx_ctx_wait               waits for the OLDEST pair in flight.  `staged` (may be NULL) receives pointers to its
+ *                              results inside the context's pinned staging -- valid until two more pairs have been
+ *                              submitted; `copy_to` (may be NULL) names caller buffers the planes are copied into as
+ *                              well (a host memcpy of 26 bytes per pixel: use `staged` where the rate matters).
+ *                              cost_* / agg_* volumes are not part of the pipelined entry.  Returns the pair's status.
+ * Results equal those of smx_ctx_stereo_pair bit for bit.  The synchronous entry refuses to run while pairs are in flight. */
+int smx_ctx_stereo_pair_async(smx_ctx* ctx, const uint8_t* gray_l, const uint8_t* gray_r, int dminl, int dminr);
+int smx_ctx_wait(smx_ctx* ctx, smx_pair_out* staged, const smx_pair_out* copy_to);
 /* Aggregation path of this context (ids as for smx_set_agg_path below). */
 int smx_ctx_set_agg_path(smx_ctx* ctx, int path);
 

@@ -75,6 +75,8 @@ SIGNATURES = {
     "smx_ctx_stereo_pair": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(PairOut)]),
     "smx_destroy": (_i, [_vp]),
     "smx_ctx_set_agg_path": (_i, [_vp, _i]),
+    "smx_ctx_stereo_pair_async": (_i, [_vp, _vp, _vp, _i, _i]),
+    "smx_ctx_wait": (_i, [_vp, C.POINTER(PairOut), C.POINTER(PairOut)]),
     "smx_dev_rgb_to_grayscale": (_i, [_PP, _vp, _i64, _i, _vp, _vp]),
     "smx_dev_cost_volume": (_i, [_PP, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "smx_dev_integral": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -577,8 +577,28 @@ struct smx_ctx {
     hipStream_t st = nullptr;
     // keys / best / dmap / mean: left view first, right view behind it (one buffer each)
     DevBuf dL, dR, keys, best, map, mean, occ, fil, ws, costL, costR, aggLR;
+    // pipelined entry (smx_ctx_stereo_pair_async): two slots of device inputs / results and pinned host staging, created
+    // on first use.  Staging of a slot: [gray_l | gray_r] going up; [best_l best_r dmap_l dmap_r occlusion filled | mean_l
+    // mean_r | status word] coming down.
+    struct Slot {
+        DevBuf in, res, mean;
+        uint8_t* h_in = nullptr;
+        char* h_out = nullptr;
+        hipEvent_t up = nullptr, done = nullptr, down = nullptr;
+        int dminl = 0, dminr = 0;
+        bool busy = false;
+    } slot[2];
+    hipStream_t st_up = nullptr, st_dn = nullptr;
+    uint64_t submitted = 0, waited = 0;
     ~smx_ctx() {
-        if (st) (void)hipStreamDestroy(st);
+        for (Slot& sl : slot) {
+            if (sl.h_in) (void)hipHostFree(sl.h_in);
+            if (sl.h_out) (void)hipHostFree(sl.h_out);
+            for (hipEvent_t e : {sl.up, sl.done, sl.down})
+                if (e) (void)hipEventDestroy(e);
+        }
+        for (hipStream_t x : {st, st_up, st_dn})
+            if (x) (void)hipStreamDestroy(x);
     }
 };
 
@@ -618,35 +638,23 @@ int smx_destroy(smx_ctx* c) {
     int dev = -1;
     (void)hipGetDevice(&dev);
     if (c->dev >= 0 && dev != c->dev) (void)hipSetDevice(c->dev);
-    if (c->st) (void)hipStreamSynchronize(c->st);
+    for (hipStream_t x : {c->st_up, c->st, c->st_dn})
+        if (x) (void)hipStreamSynchronize(x);
     delete c;
     if (dev >= 0) (void)hipSetDevice(dev);
     return SMX_OK;
 }
 
-int smx_ctx_stereo_pair(smx_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r, int dminl, int dminr,
-                        const smx_pair_out* out) {
-    SMX_ARG(c && gray_l && gray_r && out);
+// The path of one pair on the context's stream: device images in, the eight result planes out (+ the optional volumes
+// of the context).  Shared by the synchronous and the pipelined host-pointer entry.
+static int ctx_enqueue(smx_ctx* c, const uint8_t* dL, const uint8_t* dR, int dminl, int dminr, bool want_cost, bool want_agg,
+                       float* bestL, float* mapL, uint8_t* mean, float* occ, float* fil) {
     const smx_params* p = &c->p;
     const int w = c->w, h = c->h, size_d = c->size_d;
-    const size_t n = c->n, fb = n * sizeof(float), vb = fb * size_d;
-    int dev = -1;
-    SMX_HIP(hipGetDevice(&dev));
-    if (dev != c->dev) return fail(SMX_E_ARG, "smx_ctx_stereo_pair: the context lives on device %d, current device is %d", c->dev, dev);
+    const size_t n = c->n;
     hipStream_t st = c->st;
-    const bool want_cost = out->cost_l || out->cost_r;
-    const bool want_agg = out->agg_l || out->agg_r;
-    if (want_cost && !c->costL.p) { SMX_HIP(c->costL.alloc(vb)); SMX_HIP(c->costR.alloc(vb)); }
-    if (want_agg && !c->aggLR.p) SMX_HIP(c->aggLR.alloc(2 * vb));
-    uint8_t* dL = c->dL.as<uint8_t>(); uint8_t* dR = c->dR.as<uint8_t>();
-    stage_mark(ST_BEGIN, st);
-    SMX_HIP(hipMemcpyAsync(dL, gray_l, n, hipMemcpyHostToDevice, st));
-    SMX_HIP(hipMemcpyAsync(dR, gray_r, n, hipMemcpyHostToDevice, st));
-    stage_mark(ST_UPLOAD, st);
     int rc;
     const int64_t nn = (int64_t)n;
-    float* bestL = c->best.as<float>(); float* bestR = bestL + n;
-    float* mapL = c->map.as<float>();   float* mapR = mapL + n;
     int64_t* keysL = c->keys.as<int64_t>(); int64_t* keysR = keysL + n;
     // cost volumes are materialised only when the caller asks for them (main.cu:80-82) and then feed
     // the aggregation like in the reference; otherwise the slices are built on the fly inside it.
@@ -662,7 +670,7 @@ int smx_ctx_stereo_pair(smx_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r
         const float* cost[2] = {c->costL.as<float>(), c->costR.as<float>()};
         const int dmin[2] = {dminl, dminr};
         int64_t* kv[2] = {keysL, keysR};
-        uint8_t* mv[2] = {c->mean.as<uint8_t>(), c->mean.as<uint8_t>() + n};
+        uint8_t* mv[2] = {mean, mean + n};
         float* av[2] = {c->aggLR.as<float>(), want_agg ? c->aggLR.as<float>() + (size_t)size_d * n : nullptr};
         g_launches = 0;
         if ((rc = aggregate_fused(c->agg_path, p, 2, guide, other, want_cost ? cost : nullptr, w, h, dmin, 0, size_d, kv, mv,
@@ -672,19 +680,50 @@ int smx_ctx_stereo_pair(smx_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r
         const int saved = g_agg_path;
         g_agg_path = 1;
         if ((rc = smx_dev_aggregate_wta(p, dL, dR, want_cost ? c->costL.as<float>() : nullptr, w, h, dminl, 0, size_d,
-                                        keysL, c->mean.as<uint8_t>(), want_agg ? c->aggLR.as<float>() : nullptr, c->ws.p,
+                                        keysL, mean, want_agg ? c->aggLR.as<float>() : nullptr, c->ws.p,
                                         c->ws_bytes, st)))
-            return rc;
+            { g_agg_path = saved; return rc; }
         if ((rc = smx_dev_aggregate_wta(p, dR, dL, want_cost ? c->costR.as<float>() : nullptr, w, h, dminr, 0, size_d,
-                                        keysR, c->mean.as<uint8_t>() + n,
+                                        keysR, mean + n,
                                         want_agg ? c->aggLR.as<float>() + (size_t)size_d * n : nullptr, c->ws.p,
                                         c->ws_bytes, st)))
             { g_agg_path = saved; return rc; }
         g_agg_path = saved;
     }
     // main.cu:112-118 presets, winning slices, main.cu:140-155
-    if ((rc = smx_dev_finish_pair(p, keysL, w, h, dminl, dminr, dminl - 100, (float)dminl, bestL, mapL,
-                                  c->occ.as<float>(), c->fil.as<float>(), st))) return rc;
+    return smx_dev_finish_pair(p, keysL, w, h, dminl, dminr, dminl - 100, (float)dminl, bestL, mapL, occ, fil, st);
+}
+
+static int ctx_check_device(smx_ctx* c, const char* who) {
+    int dev = -1;
+    SMX_HIP(hipGetDevice(&dev));
+    if (dev != c->dev) return fail(SMX_E_ARG, "%s: the context lives on device %d, current device is %d", who, c->dev, dev);
+    return SMX_OK;
+}
+
+int smx_ctx_stereo_pair(smx_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r, int dminl, int dminr,
+                        const smx_pair_out* out) {
+    SMX_ARG(c && gray_l && gray_r && out);
+    const int size_d = c->size_d;
+    const size_t n = c->n, fb = n * sizeof(float), vb = fb * size_d;
+    int rc;
+    if ((rc = ctx_check_device(c, "smx_ctx_stereo_pair"))) return rc;
+    if (c->submitted != c->waited) return fail(SMX_E_ARG, "smx_ctx_stereo_pair: pipelined pairs are still in flight (smx_ctx_wait)");
+    hipStream_t st = c->st;
+    const bool want_cost = out->cost_l || out->cost_r;
+    const bool want_agg = out->agg_l || out->agg_r;
+    if (want_cost && !c->costL.p) { SMX_HIP(c->costL.alloc(vb)); SMX_HIP(c->costR.alloc(vb)); }
+    if (want_agg && !c->aggLR.p) SMX_HIP(c->aggLR.alloc(2 * vb));
+    uint8_t* dL = c->dL.as<uint8_t>(); uint8_t* dR = c->dR.as<uint8_t>();
+    stage_mark(ST_BEGIN, st);
+    SMX_HIP(hipMemcpyAsync(dL, gray_l, n, hipMemcpyHostToDevice, st));
+    SMX_HIP(hipMemcpyAsync(dR, gray_r, n, hipMemcpyHostToDevice, st));
+    stage_mark(ST_UPLOAD, st);
+    float* bestL = c->best.as<float>(); float* bestR = bestL + n;
+    float* mapL = c->map.as<float>();   float* mapR = mapL + n;
+    if ((rc = ctx_enqueue(c, dL, dR, dminl, dminr, want_cost, want_agg, bestL, mapL, c->mean.as<uint8_t>(), c->occ.as<float>(),
+                          c->fil.as<float>())))
+        return rc;
     struct { void* dst; const void* src; size_t b; } copies[] = {
         {out->best_l, bestL, fb}, {out->best_r, bestR, fb}, {out->dmap_l, mapL, fb},
         {out->dmap_r, mapR, fb},  {out->mean_l, c->mean.p, n}, {out->mean_r, c->mean.as<uint8_t>() + n, n},
@@ -697,6 +736,95 @@ int smx_ctx_stereo_pair(smx_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r
     stage_mark(ST_DOWNLOAD, st);
     SMX_HIP(hipStreamSynchronize(st));
     return smx_dev_agg_status(c->ws.p);
+}
+
+// ---- pipelined host-pointer entry ---------------------------------------------------------------------------------
+// Pair k uses slot k % 2.  Three streams: uploads, the path, downloads; events chain a pair through them, so that the
+// upload of pair k+1 and the download of pair k-1 run under the aggregation of pair k.
+static size_t slot_out_bytes(size_t n) { return 6 * n * sizeof(float) + 2 * n + 256; }
+
+static int ctx_async_setup(smx_ctx* c) {
+    if (c->st_up) return SMX_OK;
+    const size_t n = c->n;
+    SMX_HIP(hipStreamCreateWithFlags(&c->st_up, hipStreamNonBlocking));
+    SMX_HIP(hipStreamCreateWithFlags(&c->st_dn, hipStreamNonBlocking));
+    for (smx_ctx::Slot& sl : c->slot) {
+        SMX_HIP(sl.in.alloc(2 * n));
+        SMX_HIP(sl.res.alloc(6 * n * sizeof(float)));
+        SMX_HIP(sl.mean.alloc(2 * n));
+        SMX_HIP(hipHostMalloc((void**)&sl.h_in, 2 * n, hipHostMallocDefault));
+        SMX_HIP(hipHostMalloc((void**)&sl.h_out, slot_out_bytes(n), hipHostMallocDefault));
+        SMX_HIP(hipEventCreateWithFlags(&sl.up, hipEventDisableTiming));
+        SMX_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+        SMX_HIP(hipEventCreateWithFlags(&sl.down, hipEventDisableTiming));
+    }
+    return SMX_OK;
+}
+
+int smx_ctx_stereo_pair_async(smx_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r, int dminl, int dminr) {
+    SMX_ARG(c && gray_l && gray_r);
+    int rc;
+    if ((rc = ctx_check_device(c, "smx_ctx_stereo_pair_async"))) return rc;
+    if (c->submitted - c->waited >= 2)
+        return fail(SMX_E_ARG, "smx_ctx_stereo_pair_async: two pairs are in flight already (smx_ctx_wait takes the older one)");
+    if ((rc = ctx_async_setup(c))) return rc;
+    const size_t n = c->n, fb = n * sizeof(float);
+    smx_ctx::Slot& sl = c->slot[c->submitted & 1];
+    // the caller's images into the slot's pinned staging: the caller's buffers are free again when this call returns
+    memcpy(sl.h_in, gray_l, n);
+    memcpy(sl.h_in + n, gray_r, n);
+    sl.dminl = dminl; sl.dminr = dminr;
+    uint8_t* dL = sl.in.as<uint8_t>(); uint8_t* dR = dL + n;
+    SMX_HIP(hipMemcpyAsync(dL, sl.h_in, 2 * n, hipMemcpyHostToDevice, c->st_up));
+    SMX_HIP(hipEventRecord(sl.up, c->st_up));
+    SMX_HIP(hipStreamWaitEvent(c->st, sl.up, 0));
+    float* r = sl.res.as<float>();                       // best_l best_r dmap_l dmap_r occlusion filled
+    if ((rc = ctx_enqueue(c, dL, dR, dminl, dminr, false, false, r, r + 2 * n, sl.mean.as<uint8_t>(), r + 4 * n, r + 5 * n)))
+        return rc;
+    // status word of this pair's aggregation (the next pair's launch clears it): behind the planes in the staging
+    char* status_h = sl.h_out + 6 * fb + 2 * n;
+    SMX_HIP(hipMemcpyAsync(status_h, (const char*)align_up((size_t)c->ws.p, 256), sizeof(unsigned), hipMemcpyDeviceToHost, c->st));
+    SMX_HIP(hipEventRecord(sl.done, c->st));
+    SMX_HIP(hipStreamWaitEvent(c->st_dn, sl.done, 0));
+    SMX_HIP(hipMemcpyAsync(sl.h_out, r, 6 * fb, hipMemcpyDeviceToHost, c->st_dn));
+    SMX_HIP(hipMemcpyAsync(sl.h_out + 6 * fb, sl.mean.p, 2 * n, hipMemcpyDeviceToHost, c->st_dn));
+    SMX_HIP(hipEventRecord(sl.down, c->st_dn));
+    sl.busy = true;
+    ++c->submitted;
+    return SMX_OK;
+}
+
+int smx_ctx_wait(smx_ctx* c, smx_pair_out* staged, const smx_pair_out* copy_to) {
+    SMX_ARG(c);
+    if (c->submitted == c->waited) return fail(SMX_E_ARG, "smx_ctx_wait: no pair in flight");
+    int rc;
+    if ((rc = ctx_check_device(c, "smx_ctx_wait"))) return rc;
+    smx_ctx::Slot& sl = c->slot[c->waited & 1];
+    SMX_HIP(hipEventSynchronize(sl.down));
+    sl.busy = false;
+    ++c->waited;
+    const size_t n = c->n, fb = n * sizeof(float);
+    float* f = (float*)sl.h_out;
+    uint8_t* m = (uint8_t*)(sl.h_out + 6 * fb);
+    smx_pair_out v;
+    memset(&v, 0, sizeof(v));
+    v.best_l = f; v.best_r = f + n; v.dmap_l = f + 2 * n; v.dmap_r = f + 3 * n; v.occlusion = f + 4 * n; v.filled = f + 5 * n;
+    v.mean_l = m; v.mean_r = m + n;
+    if (staged) *staged = v;
+    if (copy_to) {
+        struct { void* dst; const void* src; size_t b; } copies[] = {
+            {copy_to->best_l, v.best_l, fb}, {copy_to->best_r, v.best_r, fb}, {copy_to->dmap_l, v.dmap_l, fb},
+            {copy_to->dmap_r, v.dmap_r, fb}, {copy_to->occlusion, v.occlusion, fb}, {copy_to->filled, v.filled, fb},
+            {copy_to->mean_l, v.mean_l, n}, {copy_to->mean_r, v.mean_r, n},
+        };
+        for (auto& cp : copies)
+            if (cp.dst) memcpy(cp.dst, cp.src, cp.b);
+    }
+    unsigned status = 0;
+    memcpy(&status, sl.h_out + 6 * fb + 2 * n, sizeof(status));
+    if (status != 0)
+        return fail(SMX_E_HIP, "fused aggregation: hand-off wait of work item %u timed out (results invalid)", status - 1);
+    return SMX_OK;
 }
 
 int smx_stereo_pair(const smx_params* p, const uint8_t* gray_l, const uint8_t* gray_r, int w, int h,

@@ -833,6 +833,81 @@ def test_persistent_context_reuses_its_buffers(orc):
 
 
 @pytest.mark.gpu
+def test_pipelined_context_equals_the_synchronous_entry(orc):
+    """smx_ctx_stereo_pair_async / smx_ctx_wait (pinned staging, upload of pair k+1 and download of pair k-1 under the
+    aggregation of pair k): five different pairs pipelined two deep through one context; every result -- read through the
+    staged pointers AND through the copy-out -- equals the synchronous smx_ctx_stereo_pair and the oracle bit for bit.
+    Also the rules of the entry: a third pair in flight and a wait without a pair are SMX_E_ARG, the synchronous entry
+    refuses to run while pairs are in flight."""
+    from stereo_matching_cuda_amd._lib import PairOut
+    L = smx.lib()
+    w, h, D = 210, 100, 9
+    n = w * h
+    params = smx.default_params()
+    ctx = C.c_void_p()
+    smx.check(L.smx_create(C.byref(params), w, h, D, C.byref(ctx)))
+    fkeys = ("best_l", "best_r", "dmap_l", "dmap_r", "occlusion", "filled")
+    mkeys = ("mean_l", "mean_r")
+    okey = {"best_l": "bestl", "best_r": "bestr", "dmap_l": "dmapl", "dmap_r": "dmapr", "occlusion": "occlusion",
+            "filled": "filled", "mean_l": "meanl", "mean_r": "meanr"}
+
+    def outbufs():
+        bufs = {k: np.empty(n, np.float32) for k in fkeys}
+        bufs.update({k: np.empty(n, np.uint8) for k in mkeys})
+        out = PairOut()
+        for k, a in bufs.items():
+            setattr(out, k, a.ctypes.data)
+        return bufs, out
+
+    try:
+        assert L.smx_ctx_wait(ctx, None, None) == -1
+        pairs = [synth.gen_pair(w, h, D, seed) for seed in (21, 22, 23, 24, 25)]
+        sync = []
+        for Il, Ir in pairs:
+            bufs, out = outbufs()
+            smx.check(L.smx_ctx_stereo_pair(ctx, Il.ctypes.data, Ir.ctypes.data, -(D - 1), 0, C.byref(out)))
+            sync.append(bufs)
+        got = []
+
+        def take():
+            bufs, out = outbufs()
+            staged = PairOut()
+            smx.check(L.smx_ctx_wait(ctx, C.byref(staged), C.byref(out)))
+            st = {}
+            for k in fkeys:
+                st[k] = np.ctypeslib.as_array(C.cast(getattr(staged, k), C.POINTER(C.c_float)), (n,)).copy()
+            for k in mkeys:
+                st[k] = np.ctypeslib.as_array(C.cast(getattr(staged, k), C.POINTER(C.c_uint8)), (n,)).copy()
+            got.append((bufs, st))
+
+        for i, (Il, Ir) in enumerate(pairs):
+            Il2, Ir2 = Il.copy(), Ir.copy()
+            smx.check(L.smx_ctx_stereo_pair_async(ctx, Il2.ctypes.data, Ir2.ctypes.data, -(D - 1), 0))
+            Il2[:] = 0; Ir2[:] = 0            # the caller's buffers are free once the call has returned
+            if i == 1:
+                # two in flight: a third is refused, and so is the synchronous entry
+                assert L.smx_ctx_stereo_pair_async(ctx, Il.ctypes.data, Ir.ctypes.data, -(D - 1), 0) == -1
+                _, out = outbufs()
+                assert L.smx_ctx_stereo_pair(ctx, Il.ctypes.data, Ir.ctypes.data, -(D - 1), 0, C.byref(out)) == -1
+            if i >= 1:
+                take()
+        take()
+        assert L.smx_ctx_wait(ctx, None, None) == -1
+        assert len(got) == len(pairs)
+        for i, (Il, Ir) in enumerate(pairs):
+            want = orc.stereo_pair(Il, Ir, D)
+            for k in fkeys + mkeys:
+                ref = np.asarray(want[okey[k]]).reshape(-1)
+                for name, a in (("sync", sync[i][k]), ("copied", got[i][0][k]), ("staged", got[i][1][k])):
+                    if a.dtype == np.float32:
+                        assert np.array_equal(a.view(np.uint32), ref.view(np.uint32)), (i, k, name)
+                    else:
+                        assert np.array_equal(a, ref), (i, k, name)
+    finally:
+        smx.check(L.smx_destroy(ctx))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("shape", ["tsukuba", "synthetic"])
 def test_fast_mode_is_close_but_not_bit_exact(tsukuba_gray, tsukuba_oracle, orc, shape):
     """the FAST aggregation (smx_set_agg_path(4): wave-parallel row prefix sums,
