@@ -97,6 +97,12 @@ __device__ unsigned long long g_stamps[10 * STAMP_SLOTS];
 #define SMX_V5_WHATIF 0
 #endif
 constexpr int WHATIF = SMX_V5_WHATIF;
+// Diagnostic build only (-DSMX_V5_MARK): comments in the ISA around the interior-path regions tools/isa_budget.py counts
+#ifdef SMX_V5_MARK
+#define V5_MARK(name) asm volatile("; MARK " name)
+#else
+#define V5_MARK(name) ((void)0)
+#endif
 #ifndef SMX_V5_WMAP
 #define SMX_V5_WMAP 0
 #endif
@@ -426,7 +432,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 }
             };
             // (two versions of the whole band: the interior one has no trace of the edge handling)
-            if (xedge || BH * ib + BH > h) run(std::true_type{}); else run(std::false_type{});
+            if (xedge || BH * ib + BH > h) run(std::true_type{}); else { V5_MARK("cost begin"); run(std::false_type{}); V5_MARK("cost end"); }
         };
         auto eval_band = [&](int ib, float* dst) {
             auto off = [&](int row, int col, int dd) {
@@ -965,7 +971,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             seen = max(seen, s_peek[sl & 1]);
             if constexpr (ROLE == ROLE_SCAN) {
                 if (!(WHATIF & 1024)) __builtin_amdgcn_s_setprio(3);
+                V5_MARK("scan begin");
                 if (!(WHATIF & 1) && sl + 1 < NI) rowscans(sl + 1, sl - 1, T1(sl + 1), T2(sl - 1), CI(sl));
+                V5_MARK("scan end");
                 __builtin_amdgcn_s_setprio(0);
             } else if constexpr (ROLE == ROLE_COST) {
                 if (lane == 63) {
@@ -996,7 +1004,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
 #define V5_P1E(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::true_type{}, std::integral_constant<bool, TT == 0>{}, sl, t1, rv);
                     if (border) { V5_R1(0, 2) V5_R1(1, 2) V5_R1(2, 2) V5_R1(3, 2) V5_R1(4, 2) V5_R1(5, 2) V5_R1(6, 2) V5_R1(7, 2) V5_R1(8, 2) V5_R1(9, 2) }
                     else if (xedge || k == 0) { V5_P1E(0) V5_P1E(2) V5_P1E(4) V5_P1E(6) V5_P1E(8) }
-                    else { V5_P1(0) V5_P1(2) V5_P1(4) V5_P1(6) V5_P1(8) }
+                    else { V5_MARK("s1rows begin"); V5_P1(0) V5_P1(2) V5_P1(4) V5_P1(6) V5_P1(8) V5_MARK("s1rows end"); }
                     }
 #undef V5_R1
 #undef V5_P1
@@ -1008,6 +1016,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     if (succ && tid == 64 * 2 * NS1 - 1 && sl >= 1) flag_store(myflag, (unsigned)sl);
                     // the a/b band sl-2 (scanned in pass sl-1) out of its tile; the record of pass sl-1 (index sl): halo of that
                     // band, carries of stage-1 band sl
+                    V5_MARK("s2head begin");
                     const float* const t2 = T2(sl);
 #pragma unroll
                     for (int t = 0; t < BH; ++t) r2[t] = tile_rd(t2 + t * RS + jt);
@@ -1027,6 +1036,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r2[0]), "+v"(r2[1]), "+v"(r2[2]), "+v"(r2[3]), "+v"(r2[4]), "+v"(r2[5]),
                                  "+v"(r2[6]), "+v"(r2[7]), "+v"(r2[8]), "+v"(r2[9]) :: "memory");
                     if (lane == 0) __hip_atomic_fetch_add(&s_x1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    V5_MARK("s2head end");
                     V5_STAMP(3);
                     V5_STAMP(4);
                     if (sl >= 2) {
@@ -1037,7 +1047,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
 #define V5_R2(TT, B) row2(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, sl);
 #define V5_P2(TT) rows2_pair(std::integral_constant<int, BH * PAR + TT>{}, sl);
                         if (border) { V5_R2(0, true) V5_R2(1, true) V5_R2(2, true) V5_R2(3, true) V5_R2(4, true) V5_R2(5, true) V5_R2(6, true) V5_R2(7, true) V5_R2(8, true) V5_R2(9, true) }
-                        else { V5_P2(0) V5_P2(2) V5_P2(4) V5_P2(6) V5_P2(8) }
+                        else { V5_MARK("s2rows begin"); V5_P2(0) V5_P2(2) V5_P2(4) V5_P2(6) V5_P2(8) V5_MARK("s2rows end"); }
                         }
 #undef V5_R2
 #undef V5_P2
@@ -1057,7 +1067,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             }
             if constexpr (ROLE == ROLE_S1) {
                 // (the halo is that of the a/b band sl, which the comb rows above have just written into the same tile)
+                V5_MARK("s1handin begin");
                 if (pred && sl + 2 < NI) { cin1 = CI(sl + 1); tile2 = T2(sl); hand_in(sl >= 0); }
+                V5_MARK("s1handin end");
             }
             V5_STAMP(5);
         };

@@ -11,10 +11,10 @@ wl = args.pop(0) if args and not args[0].isdigit() else 'kitti'
 w,h,D = synth.SHAPES[wl]
 Il,Ir = synth.gen_pair(w,h,D,synth.SEEDS.get(wl, 1))
 dl,dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
-reps = 20 if wl == 'kitti' else 3
+reps = 100 if wl == 'kitti' else 5
 for N in [int(a) for a in args] or (1,2,4,8):
     pipe = PairPipeline(w,h,D,s_begin=0,s_end=D//N)
-    for _ in range(2): pipe.run(dl,dr)
+    for _ in range(10): pipe.run(dl,dr)
     torch.cuda.synchronize(); t=time.perf_counter()
     for _ in range(reps): pipe.run(dl,dr)
     torch.cuda.synchronize(); dt=(time.perf_counter()-t)/reps*1e3
