@@ -1,4 +1,6 @@
-// Minimal PNG reader / writer on zlib.  Own code (the reference vendors stb for this).
+// Minimal PNG reader / writer.  Own code (the reference vendors stb for this).  Reading inflates with zlib; the 8-bit
+// writer produces the very byte stream the reference's writer does (see `Stream of the reference's files` below), the
+// 16-bit writer (no counterpart in the reference) deflates with zlib.
 #include "png_io.h"
 
 #include <zlib.h>
@@ -105,20 +107,178 @@ unsigned char* smx_png_load(const char* path, int* w, int* h, int* channels) {
     return out;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Stream of the reference's files.  main.cu:162-181 writes its twelve PNGs through the single-header writer it vendors
+// (stb_image_write, public domain); tests/golden/tsukuba/*.png are those files.  A PNG is not a canonical encoding of its
+// pixels: the bytes depend on the row filters chosen and on every match the deflater takes.  This is a restatement of
+// that writer's DECISIONS (not of its code), so that `cmp` of our outputs against the reference's files succeeds:
+//   rows    each row is tried with the five filter types; the one with the smallest sum of |signed byte| wins, the first
+//           on ties.  In the first image row the writer's variants differ from the PNG definition applied to a zero
+//           row above only in what it computes, never in the result (Up = None, Average = half of left, Paeth = Sub),
+//           so the plain definitions with a zero previous row give the same bytes.
+//   zlib    header 78 5E, ONE block of fixed Huffman codes (RFC 1951 3.2.6), Adler-32 trailer.
+//   matches positions are hashed on three bytes into 16384 chains; a chain that has grown to 16 entries is cut to its
+//           newer 8 before the next insert; only positions where a match or literal STARTS are inserted.  The longest
+//           candidate within 32 KiB wins, the newer one on ties, nothing shorter than 3; a match is dropped for a literal
+//           when some candidate at the next byte is strictly longer (one step of lazy evaluation).  The last three bytes
+//           are always literals.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace refstream {
+
+struct Bits {
+    std::vector<unsigned char>& out;
+    uint32_t acc = 0;
+    int n = 0;
+    void put(uint32_t v, int bits) {               // LSB first, as deflate packs
+        acc |= v << n;
+        n += bits;
+        while (n >= 8) { out.push_back((unsigned char)(acc & 0xFFu)); acc >>= 8; n -= 8; }
+    }
+    void put_code(uint32_t code, int bits) {       // Huffman codes go in MSB first
+        uint32_t r = 0;
+        for (int i = 0; i < bits; ++i) r |= ((code >> i) & 1u) << (bits - 1 - i);
+        put(r, bits);
+    }
+    void litlen(int sym) {                         // the fixed literal/length code
+        if (sym <= 143) put_code(0x30u + (uint32_t)sym, 8);
+        else if (sym <= 255) put_code(0x190u + (uint32_t)(sym - 144), 9);
+        else if (sym <= 279) put_code((uint32_t)(sym - 256), 7);
+        else put_code(0xC0u + (uint32_t)(sym - 280), 8);
+    }
+    void align() { if (n) put(0, 8 - n); }
+};
+
+inline uint32_t chain_of(const unsigned char* p) {
+    uint32_t h = (uint32_t)p[0] + ((uint32_t)p[1] << 8) + ((uint32_t)p[2] << 16);
+    h ^= h << 3;  h += h >> 5;
+    h ^= h << 4;  h += h >> 17;
+    h ^= h << 25; h += h >> 6;
+    return h & 16383u;
+}
+inline int run(const unsigned char* a, const unsigned char* b, long limit) {
+    const long m = limit < 258 ? limit : 258;
+    long i = 0;
+    while (i < m && a[i] == b[i]) ++i;
+    return (int)i;
+}
+
+std::vector<unsigned char> deflate(const std::vector<unsigned char>& in) {
+    // RFC 1951 3.2.5: base values and extra bits of the length codes 257.. and of the distance codes
+    static const int len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const int len_bits[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    static const int dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+    static const int dist_bits[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+    constexpr size_t KEEP = 8;                     // chain entries kept when a chain is cut (the writer's default level)
+    const long N = (long)in.size();
+    const unsigned char* d = in.data();
+    std::vector<unsigned char> out = {0x78, 0x5E};
+    Bits b{out};
+    b.put(1, 1);                                   // last block
+    b.put(1, 2);                                   // fixed codes
+    std::vector<std::vector<long>> chains(16384);
+    long i = 0;
+    while (i < N - 3) {
+        std::vector<long>& c = chains[chain_of(d + i)];
+        int best = 3;
+        long at = -1;
+        for (long p : c)
+            if (p > i - 32768) {
+                const int m = run(d + p, d + i, N - i);
+                if (m >= best) { best = m; at = p; }
+            }
+        if (c.size() == 2 * KEEP) c.erase(c.begin(), c.begin() + KEEP);
+        c.push_back(i);
+        if (at >= 0) {
+            for (long p : chains[chain_of(d + i + 1)])
+                if (p > i - 32767 && run(d + p, d + i + 1, N - i - 1) > best) { at = -1; break; }
+        }
+        if (at >= 0) {
+            const int dist = (int)(i - at);
+            int k = 28;
+            while (k > 0 && len_base[k] > best) --k;
+            b.litlen(257 + k);
+            if (len_bits[k]) b.put((uint32_t)(best - len_base[k]), len_bits[k]);
+            int q = 29;
+            while (q > 0 && dist_base[q] > dist) --q;
+            b.put_code((uint32_t)q, 5);
+            if (dist_bits[q]) b.put((uint32_t)(dist - dist_base[q]), dist_bits[q]);
+            i += best;
+        } else {
+            b.litlen(d[i]);
+            ++i;
+        }
+    }
+    for (; i < N; ++i) b.litlen(d[i]);
+    b.litlen(256);
+    b.align();
+    uint32_t s1 = 1, s2 = 0;                       // Adler-32
+    for (long k = 0; k < N; ++k) { s1 = (s1 + d[k]) % 65521u; s2 = (s2 + s1) % 65521u; }
+    out.push_back((unsigned char)(s2 >> 8)); out.push_back((unsigned char)s2);
+    out.push_back((unsigned char)(s1 >> 8)); out.push_back((unsigned char)s1);
+    return out;
+}
+
+// filtered scanlines: [type byte | w * channels bytes] per row
+std::vector<unsigned char> filter_rows(const unsigned char* px, int w, int h, int ch) {
+    const size_t stride = (size_t)w * ch;
+    std::vector<unsigned char> rows((stride + 1) * h), zero(stride, 0), cand(stride);
+    for (int y = 0; y < h; ++y) {
+        const unsigned char* cur = px + stride * y;
+        const unsigned char* up = y ? cur - stride : zero.data();
+        long best_sum = 0x7fffffffL;
+        int best_t = 0;
+        unsigned char* dst = &rows[(stride + 1) * y];
+        for (int t = 0; t < 5; ++t) {
+            long sum = 0;
+            for (size_t i = 0; i < stride; ++i) {
+                const int a = i >= (size_t)ch ? cur[i - ch] : 0, bb = up[i], c = i >= (size_t)ch ? up[i - ch] : 0;
+                int pred = 0;
+                switch (t) {
+                    case 1: pred = a; break;
+                    case 2: pred = bb; break;
+                    case 3: pred = (a + bb) >> 1; break;
+                    case 4: pred = paeth(a, bb, c); break;
+                    default: break;
+                }
+                cand[i] = (unsigned char)(cur[i] - pred);
+                sum += abs((int)(signed char)cand[i]);
+            }
+            if (sum < best_sum) {
+                best_sum = sum;
+                best_t = t;
+                dst[0] = (unsigned char)t;
+                memcpy(dst + 1, cand.data(), stride);
+            }
+        }
+        (void)best_t;
+    }
+    return rows;
+}
+
+}  // namespace refstream
+
 // 8-bit (bytes_per_sample = 1) or 16-bit big-endian samples (bytes_per_sample = 2, already in file order)
 static int png_write_impl(const char* path, int w, int h, int channels, int bytes_per_sample,
                           const unsigned char* data) {
     const int ctype = channels == 1 ? 0 : channels == 3 ? 2 : channels == 2 ? 4 : channels == 4 ? 6 : -1;
     if (ctype < 0 || w <= 0 || h <= 0 || w > SMX_PNG_MAX_DIM || h > SMX_PNG_MAX_DIM || !data) return 0;
     const size_t stride = (size_t)w * channels * bytes_per_sample;
-    std::vector<unsigned char> raw((stride + 1) * h);
-    for (int y = 0; y < h; ++y) {
-        raw[(stride + 1) * y] = 0;  // filter type None
-        memcpy(&raw[(stride + 1) * y + 1], data + stride * y, stride);
+    std::vector<unsigned char> comp;
+    uLongf clen = 0;
+    if (bytes_per_sample == 1) {
+        // the reference's stream (main.cu:162-181): see refstream above
+        comp = refstream::deflate(refstream::filter_rows(data, w, h, channels));
+        clen = (uLongf)comp.size();
+    } else {
+        std::vector<unsigned char> raw((stride + 1) * h);
+        for (int y = 0; y < h; ++y) {
+            raw[(stride + 1) * y] = 0;  // filter type None
+            memcpy(&raw[(stride + 1) * y + 1], data + stride * y, stride);
+        }
+        clen = compressBound((uLong)raw.size());
+        comp.resize(clen);
+        if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return 0;
     }
-    uLongf clen = compressBound((uLong)raw.size());
-    std::vector<unsigned char> comp(clen);
-    if (compress2(comp.data(), &clen, raw.data(), (uLong)raw.size(), 6) != Z_OK) return 0;
     std::vector<unsigned char> out = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
     unsigned char ihdr[13];
     ihdr[0] = w >> 24; ihdr[1] = w >> 16; ihdr[2] = w >> 8; ihdr[3] = w;

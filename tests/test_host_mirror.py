@@ -173,6 +173,10 @@ def test_drop_in_main_modes(binary, golden, tmp_path, flags):
     for name in OUTPUTS:
         got = np.asarray(PIL.open(data / (name + ".png")))
         assert np.array_equal(got, golden[name]), name
+        # not only the pixels -- the FILES equal the reference's own outputs byte for byte (main.cu:162-181
+        # writes them through stb_image_write; host/png_io.cpp restates that writer's filter and match decisions)
+        ref = open(os.path.join(ROOT, "tests", "golden", "tsukuba", name + ".png"), "rb").read()
+        assert (data / (name + ".png")).read_bytes() == ref, name
     # dataset-style outputs: positive disparities of the filled left map
     raw = pfm.read_bytes()
     head, rest = raw.split(b"\n", 3)[:3], raw.split(b"\n", 3)[3]
@@ -211,6 +215,41 @@ def test_main_reports_unwritable_output_directory(binary, tmp_path):
     r = subprocess.run([binary, str(data / "tsukuba0.png"), str(data / "tsukuba1.png"), "-3", "0",
                         str(tmp_path / "missing_dir")], cwd=tmp_path, capture_output=True, text=True, timeout=300)
     assert r.returncode == 1 and "could not be written" in r.stderr
+
+
+def test_png_writer_reproduces_the_reference_files_byte_for_byte(tmp_path):
+    """SURVEY 8 f1 on the CPU: each of the twelve PNGs the reference wrote for Tsukuba (tests/golden/tsukuba, main.cu:162-181
+    through its vendored stb_image_write) is decoded and written again by host/png_io.cpp; the new file must `cmp` equal.
+    A PNG is not canonical in its pixels -- this pins the row-filter choice (minimum sum of |signed byte|, first on ties),
+    the three-byte hash chains cut from 16 to their newer 8, the one lazy step and the fixed-Huffman block."""
+    exe = str(tmp_path / "reencode")
+    src = tmp_path / "reencode.cpp"
+    src.write_text('#include "png_io.h"\n#include <cstdlib>\n'
+                   'int main(int c, char** v) { int w, h, ch; unsigned char* p = smx_png_load(v[1], &w, &h, &ch);'
+                   ' if (!p) return 2; int ok = smx_png_write(v[2], w, h, ch, p); std::free(p); return ok ? 0 : 3; }\n')
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + HOST, str(src), os.path.join(HOST, "png_io.cpp"),
+                           "-o", exe, "-lz"])
+    gdir = os.path.join(ROOT, "tests", "golden", "tsukuba")
+    assert len(OUTPUTS) == 12
+    for name in OUTPUTS:
+        ref = os.path.join(gdir, name + ".png")
+        out = tmp_path / (name + ".png")
+        subprocess.check_call([exe, ref, str(out)])
+        assert out.read_bytes() == open(ref, "rb").read(), name
+    # a few synthetic shapes through the writer and back through the reader (rows of one pixel, RGB, RGBA, runs > 258)
+    rt = tmp_path / "roundtrip.cpp"
+    rt.write_text('#include "png_io.h"\n#include <cstdlib>\n#include <cstring>\n#include <vector>\n'
+                  'int main() { const int shapes[][3] = {{1,1,1},{1,7,3},{5,1,4},{700,3,1},{33,29,2},{64,64,3}};'
+                  ' for (auto& s : shapes) { int w = s[0], h = s[1], ch = s[2]; std::vector<unsigned char> a((size_t)w*h*ch);'
+                  ' unsigned x = 12345u + w; for (size_t i = 0; i < a.size(); ++i) { x = x * 1664525u + 1013904223u;'
+                  ' a[i] = (i / 97) % 3 == 0 ? 7 : (unsigned char)(x >> 24); }'
+                  ' if (!smx_png_write("rt.png", w, h, ch, a.data())) return 1; int W, H, C;'
+                  ' unsigned char* p = smx_png_load("rt.png", &W, &H, &C); if (!p || W != w || H != h || C != ch ||'
+                  ' std::memcmp(p, a.data(), a.size())) return 2; std::free(p); } return 0; }\n')
+    exe2 = str(tmp_path / "roundtrip")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I" + HOST, str(rt), os.path.join(HOST, "png_io.cpp"),
+                           "-o", exe2, "-lz"])
+    assert subprocess.run([exe2], cwd=tmp_path).returncode == 0
 
 
 def test_png_reader_rejects_malformed_files(tmp_path):
