@@ -1383,7 +1383,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     // The comb walker (smx_agg_v5.hip) serves the hot case: radius 9, costs built from the images, exact mode.
     // walker: 0 = choose, 4 = the ring walker of this file.  Both share this orchestration: image planes, guidance
     // statistics, chunking, WTA pass; only the strip / band geometry and the records differ.
-    const bool use_v5 = walker != 4 && !use_cost && !fast && v5_supported(p) &&
+    const bool use_v5 = walker != 4 && !use_cost && v5_supported(p) &&
                         (size_t)h * ((size_t)w + 2 * v4::PADX) * 24 < 0x80000000ull;   // (its planes share one 32-bit-offset descriptor)
     if (walker_used) *walker_used = use_v5 ? 5 : 4;
     if (use_v5) {
@@ -1547,6 +1547,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                 memcpy(&uc, &hc, 2); memcpy(&ug, &hg, 2);
                 b.th2 = (unsigned)uc | ((unsigned)ug << 16);
             }
+            b.fast = fast ? 1 : 0;
             b.qperm = own_q ? 1 : 0;
             b.q_plane = qplane;
             rc = v5_launch(b, st);

@@ -209,7 +209,10 @@ __device__ __forceinline__ float mix_mul_lo_v(unsigned h2, float v) {
 __device__ __forceinline__ f2 tile_rd(const float* p) { return (f2){p[0], p[P1]}; }
 __device__ __forceinline__ void tile_wr(float* p, f2 v) { p[0] = v.x; p[P1] = v.y; }
 
-template <int DUMMY>
+// FASTK = 1: the FAST mode (smx_set_agg_path(4)): window means by multiplication with the rounded reciprocal of the area
+// instead of the correctly rounded division, no exactness vote -- the same sums in the same order, at most an ulp or two away
+// per mean; NOT bit-exact, never the default
+template <int FASTK>
 __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     __shared__ __attribute__((aligned(16))) float tile1[NT1][TILE_F];
     __shared__ __attribute__((aligned(16))) float tile2s[NT2][TILE_F];
@@ -610,7 +613,8 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 const f2 u0 = ring[SL] - ring[SL01];
                 if (il0 && k == 0) u = u0;
             }
-            const f2 m = div_ca(u, area_of(BH * i - R + T, BORDERc));   // (mean_p, mean_Ip); no window sum of p, I p can be tiny (smx_agg_v5.h)
+            const f2 ca1 = area_of(BH * i - R + T, BORDERc);
+            const f2 m = FASTK ? div_ca_q(u, ca1) : div_ca(u, ca1);   // (mean_p, mean_Ip); no window sum of p, I p can be tiny (smx_agg_v5.h)
             const f2 g = gq[T];
             // compute_ak_and_bk guidedFilter.cu:345-354
             const float mm = g.x * m.x;
@@ -637,12 +641,12 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             V5_BOX(u, SL, SL01);
             const int yq = BH * (i - 2) - 2 * R + T;
             const f2 ca = area_of(yq, BORDERc);
-            f2 m = div_ca(u, ca);
+            f2 m = FASTK ? div_ca_q(u, ca) : div_ca(u, ca);
             // tiny (or zero) window sums of a, b take the true division (wave-uniform, rare); lanes without an
             // output do not vote
-            float amin;
-            asm("v_min_f32 %0, |%1|, |%2|" : "=v"(amin) : "v"(u.x), "v"(u.y));
-            if ((__builtin_amdgcn_ballot_w64(!(amin >= 0x1p-100f)) & okmask) != 0) {
+            float amin = 1.0f;
+            if (!FASTK) asm("v_min_f32 %0, |%1|, |%2|" : "=v"(amin) : "v"(u.x), "v"(u.y));
+            if (!FASTK && (__builtin_amdgcn_ballot_w64(!(amin >= 0x1p-100f)) & okmask) != 0) {
                 asm volatile("; exact-division slow path");
                 m.x = 1.0f * u.x / ca.y;
                 m.y = 1.0f * u.y / ca.y;
@@ -696,13 +700,12 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 const f2 u0b = sb - ring[S01b];
                 if (il0 && k == 0) ub = u0b;
             }
-            const f2 ea = div_ca_e(qa, ua, ca_i);
             const f2 qb = div_ca_q(ub, ca_i);
-            const f2 ma = div_ca_m(ea, qa, ca_i);      // (mean_p, mean_Ip)
-            const f2 eb = div_ca_e(qb, ub, ca_i);
+            f2 ma = qa, mb = qb;                       // (mean_p, mean_Ip)
+            if constexpr (!FASTK) ma = div_ca_m(div_ca_e(qa, ua, ca_i), qa, ca_i);
             const f2 ga = gq[T0], gb = gq[T0 + 1];
             const float mma = ga.x * ma.x;             // compute_ak_and_bk guidedFilter.cu:345-354
-            const f2 mb = div_ca_m(eb, qb, ca_i);
+            if constexpr (!FASTK) mb = div_ca_m(div_ca_e(qb, ub, ca_i), qb, ca_i);
             const float ta = ma.y - mma;
             const float mmb = gb.x * mb.x;
             const float aka = 1.0f * ta * ga.y;
@@ -737,15 +740,16 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             ub = ub - ring[S01b];
             const f2 qa = div_ca_q(ua, ca_i);
             ub = box_top(ub, ring[S01b]);
-            const f2 ea = div_ca_e(qa, ua, ca_i);
             const f2 qb = div_ca_q(ub, ca_i);
-            f2 ma = div_ca_m(ea, qa, ca_i);
-            const f2 eb = div_ca_e(qb, ub, ca_i);
-            float amin;
-            asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(amin) : "v"(ua.x), "v"(ua.y), "v"(ub.x));
-            f2 mb = div_ca_m(eb, qb, ca_i);
-            asm("v_min_f32 %0, %1, |%2|" : "=v"(amin) : "v"(amin), "v"(ub.y));
-            if ((__builtin_amdgcn_ballot_w64(!(amin >= 0x1p-100f)) & okmask) != 0) {
+            f2 ma = qa, mb = qb;
+            float amin = 1.0f;
+            if constexpr (!FASTK) {
+                ma = div_ca_m(div_ca_e(qa, ua, ca_i), qa, ca_i);
+                asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(amin) : "v"(ua.x), "v"(ua.y), "v"(ub.x));
+                mb = div_ca_m(div_ca_e(qb, ub, ca_i), qb, ca_i);
+                asm("v_min_f32 %0, %1, |%2|" : "=v"(amin) : "v"(amin), "v"(ub.y));
+            }
+            if (!FASTK && (__builtin_amdgcn_ballot_w64(!(amin >= 0x1p-100f)) & okmask) != 0) {
                 asm volatile("; exact-division slow path");
                 ma.x = 1.0f * ua.x / ca_i.y; ma.y = 1.0f * ua.y / ca_i.y;
                 mb.x = 1.0f * ub.x / ca_i.y; mb.y = 1.0f * ub.y / ca_i.y;
@@ -1246,7 +1250,8 @@ int v5_launch(const v5::Args& a, hipStream_t st) {
     }
     const int slots = per_cu * ncu;
     const int grid = a.nitems < slots ? a.nitems : slots;
-    hipLaunchKernelGGL((v5::k_v5_walk<0>), dim3((unsigned)grid), dim3(v5::NT), 0, st, a);
+    if (a.fast) hipLaunchKernelGGL((v5::k_v5_walk<1>), dim3((unsigned)grid), dim3(v5::NT), 0, st, a);
+    else hipLaunchKernelGGL((v5::k_v5_walk<0>), dim3((unsigned)grid), dim3(v5::NT), 0, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

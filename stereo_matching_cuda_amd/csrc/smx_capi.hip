@@ -70,7 +70,7 @@ static int aggregate_fused(int path, const smx_params* p, int nviews, const uint
     if (path == 5 && (cost_in || !v5_supported(p)))
         return fail(SMX_E_ARG, "aggregation path 5 (comb walker) needs radius 9, costs built from the images and default-like cost parameters");
     int rc = aggregate_v4(p, nviews, d_guide, d_other, d_cost, w, h, dmin, s_begin, s_end, d_keys, d_mean_u8,
-                          d_agg, d_ws, ws_bytes, st, launches, path == 4, path == 3 || path == 4 ? 4 : 0, &used);
+                          d_agg, d_ws, ws_bytes, st, launches, path == 4, path == 3 ? 4 : 0, &used);
     if (rc) return rc;
     g_last_path = path == 4 ? 4 : (used == 5 ? 5 : 2);
     return SMX_OK;

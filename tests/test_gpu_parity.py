@@ -910,13 +910,14 @@ def test_pipelined_context_equals_the_synchronous_entry(orc):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", ["tsukuba", "synthetic"])
 def test_fast_mode_is_close_but_not_bit_exact(tsukuba_gray, tsukuba_oracle, orc, shape):
-    """the FAST aggregation (smx_set_agg_path(4): wave-parallel row prefix sums,
-    i.e. re-associated additions) is reported separately and never the default.  What re-association costs
-    is the rounding noise of the integral image itself: an integral value is ~1e5 .. 1e6 at these sizes (ulp
-    0.01 .. 0.1) and a box mean divides a difference of four of them by 361, so the aggregated volume moves by
-    up to ~1e-3 relative (measured and printed; bound asserted: 5e-3) -- an order of magnitude more than the
-    1e-4 the survey hoped for -- and the labels flip where the two best costs of a pixel are closer than that
-    (the count is printed).  The exact mode pays for having neither."""
+    """the FAST aggregation (smx_set_agg_path(4)) is reported separately and never the default.
+    On the comb walker it keeps every sum and its order and only replaces the two correctly rounded divisions of a cell by
+    multiplications with the rounded reciprocal of the window area (and drops the exactness vote): a window mean moves by
+    an ulp.  Even that is NOT within the 1e-4 `north_star` hoped for: a_k = (mean_Ip - mean_I * mean_p) / (var + eps)
+    subtracts two numbers that agree in their first three or four digits, so one ulp in a mean is ~1e-4 .. 1e-3 of the
+    covariance and shows up as 2.4e-4 relative in the aggregated volume (measured and printed; bound asserted: 1e-3).  No
+    re-ordered or approximately divided f32 implementation can promise 1e-4 on this filter; the exact mode is 2 % slower
+    than this one.  Labels flip only where the two best costs of a pixel are that close (count printed)."""
     if shape == "tsukuba":
         Il, Ir = tsukuba_gray
         D, want, kw = 16, tsukuba_oracle, dict(dminl=-15, dminr=0)
@@ -929,7 +930,7 @@ def test_fast_mode_is_close_but_not_bit_exact(tsukuba_gray, tsukuba_oracle, orc,
     for v in "lr":
         got, ref = np.asarray(r["agg" + v], np.float64), np.asarray(want["agg" + v], np.float64).reshape(r["agg" + v].shape)
         rel = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-3)
-        assert rel.max() <= 5e-3, (v, rel.max())
+        assert rel.max() <= 1e-3, (v, rel.max())
         worst = max(locals().get("worst", 0.0), float(rel.max()))
         flips[v] = int((np.asarray(r["dmap" + v]) != np.asarray(want["dmap" + v]).reshape(r["dmap" + v].shape)).sum())
         assert np.array_equal(r["mean" + v], np.asarray(want["mean" + v]).reshape(r["mean" + v].shape))
