@@ -2,19 +2,35 @@
 // cost build -> integral (p, I*p) -> box -> a_k, b_k -> integral (a, b) -> box -> q in ONE kernel.
 // Reference: guidedFilter.cu:171-238, costVolume.cu:163-190, integral.cu:78-131.
 //
-// What changed against smx_agg_v4.hip: the integral images no longer live in LDS rings.  A work item is a strip
-// of OWS = 285 output columns of one slice-view, walked top -> bottom in bands of BH = 10 rows by one 640-thread
-// workgroup (two per CU).  Its 304 integral-image columns are dealt to COMB lanes: lane i of a 16-lane DPP row
-// with residue r owns column base + 19 i + r, so
-//   * the left box tap (2R+1 = 19 columns to the left) is always lane i-1 of the same DPP row: `row_shr:1` fused
-//     into the subtraction / addition, no LDS access, no bank conflict;
+// What changed against smx_agg_v4.hip: the integral images no longer live in LDS rings.  A work item is a strip of
+// OWS = 19 (L - 1) output columns of one slice-view, walked top -> bottom in bands of BH = 10 rows by one workgroup (two
+// per CU).  Its 19 L integral-image columns are dealt to COMB lanes: lane i of a comb with residue r owns column
+// base + 19 i + r, so
+//   * the left box tap (2R+1 = 19 columns to the left) is always lane i-1 of the same comb: `wave_shr:1` (`row_shr:1` for
+//     combs of 16) fused into the subtraction / addition, no LDS access, no bank conflict;
 //   * the column prefix sum S[y][c] = S[y-1][c] + R[y][c] is a register of the lane, and the 19 rows of history the
 //     top taps need are a 20-slot register ring of the lane (static slots: the band loop is unrolled over two
 //     bands = one turn of the ring);
-//   * only the ROW prefix sums go through LDS: a band tile of 10 rows x 304 columns x 2 components per stage,
-//     scanned in place by one wave (lane = (stage, row, component), four columns per LDS instruction, the
-//     reference's left -> right order) and read once by the comb lanes.
-// Waves 0..4 are the combs of stage 1 (p, I p -> a_k, b_k), waves 5..9 those of stage 2 (a, b -> q).
+//   * only the ROW prefix sums go through LDS: a band tile of 10 rows x 19 L columns x 2 components per stage, scanned in
+//     place by one wave (lane = (stage, row, component), four columns per LDS instruction, the reference's left -> right
+//     order) and read once by the comb lanes.
+//
+// Default build, SMX_V5_L = 9 (smx_agg_v5.h), the PIPELINED form: 512 threads = 3 comb waves of stage 1 (p, I p -> a_k,
+// b_k), 3 comb waves of stage 2 (a, b -> q), one ROW-SCAN wave and one COST wave; seven combs of nine lanes per comb
+// wave, 152 output columns per strip, 128 VGPRs, 79 KB of LDS: two workgroups per CU.  One workgroup barrier (ordering
+// LDS only) per band; in slot sl of an item
+//   cost wave      evaluates the stage-1 inputs of band sl+2 (packed-half arithmetic, exact: cost_trunc_h2) -> tile 1[(sl+2)%3]
+//   scan wave      row prefix of stage 1 on band sl+1 (tile 1[(sl+1)%3]) and of stage 2 on the a/b band sl-1 (tile 2[(sl-1)%2])
+//   stage-1 combs  S1 += R1 of band sl, box, division -> a_k, b_k of rows [10 sl - 9, 10 sl + 1) -> tile 2[sl%2];
+//                  then the left neighbour's record of pass sl+1 (halo columns of stage 2, row carries of stage 1) -> LDS
+//   stage-2 combs  the a/b band sl-2 out of tile 2[sl%2] into registers (first thing: the stage-1 waves wait for that
+//                  through an LDS counter before their first store), hand-off record of pass sl-1 -> global (sc1);
+//                  S2 += R2, box, division, q rows [10 sl - 38, 10 sl - 28) -> HBM
+// SMX_V5_L = 12 / 16 build the earlier three-barrier forms (W / R / X phases, the row scans on wave 0): kept as A/B
+// variants (tools/exp_build.sh), not shipped.
+// Hand-off, tickets and the bounded flag waits are those of smx_agg_v4.hip (strip-major tickets: the left neighbour of
+// an item always holds an earlier ticket); every wave takes the flag value it acts on from an LDS word written in the
+// slot before (s_peek), so that all eight waves agree on whether the slot has the extra barrier of a wait.
 //
 // Exactness (all checked bit for bit by the CPU model tools/v5_model.cpp against the oracle): virtual rows and
 // columns outside the image hold -0, the exact additive identity, so the clamped window corners of
@@ -24,17 +40,6 @@
 // path can be -0: every p is >= +0 (costVolume.cu:187) and neither a_k nor b_k can be -0 (x - y == -0 only for
 // x == -0).  That argument needs costs built from the images, so this kernel serves SRC_IMG only; materialised
 // cost volumes and other radii stay on smx_agg_v4.hip.
-//
-// Iteration i of an item (three workgroup barriers, each ordering LDS only):
-//   W(i)  waves 0..4: a_k, b_k of band i-1 (registers since X(i-1)) -> tile 2; hand-off threads: the left
-//         neighbour's record i (stage-2 halo columns -> tile 2, stage-1 row carries -> LDS); everybody: loads of
-//         the stage-1 inputs of band i+1
-//   R(i)  wave 0: row scans of stage 1 (band i, tile 1[i&1]) and stage 2 (a/b band i-1, tile 2)
-//         waves 1..9: evaluate band i+1's costs -> tile 1[(i+1)&1]; drain of the record stores of X(i-1)
-//   X(i)  waves 0..4: S1 += R1, box -> a_k, b_k of rows [10 i - 9, 10 i + 1)   (registers)
-//         waves 5..9: S2 += R2, box -> q rows [10 i - 28, 10 i - 18) -> HBM; record i -> global (sc1)
-// Hand-off, tickets and the bounded flag waits are those of smx_agg_v4.hip (strip-major tickets: the left
-// neighbour of an item always holds an earlier ticket).
 //
 // Must be compiled with -ffp-contract=off.
 #include <stdlib.h>
