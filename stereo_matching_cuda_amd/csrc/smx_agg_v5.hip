@@ -83,7 +83,7 @@ static_assert(REC_U == NHU + NCU, "record layout");
 // Diagnostic build only (-DSMX_V5_STAMPS=<item>): every wave of one work item records the shader clock at the
 // start and end of its work in the W, R and X phases (the gaps are barrier waits); the product build has no stamp.
 #ifdef SMX_V5_STAMPS
-constexpr int STAMP_W = 6;
+constexpr int STAMP_W = 12;     // 0..5: slot phases; 6..10: after each of the five row pairs (comb waves) / quarters of the scan / cost batches
 constexpr int STAMP_SLOTS = STAMP_W * 48;
 __device__ unsigned long long g_stamps[10 * STAMP_SLOTS];
 #define V5_STAMP(n)                                                                          \
@@ -1013,7 +1013,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
 #define V5_P1E(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::true_type{}, std::integral_constant<bool, TT == 0>{}, sl, t1, rv);
                     if (border) { V5_R1(0, 2) V5_R1(1, 2) V5_R1(2, 2) V5_R1(3, 2) V5_R1(4, 2) V5_R1(5, 2) V5_R1(6, 2) V5_R1(7, 2) V5_R1(8, 2) V5_R1(9, 2) }
                     else if (xedge || k == 0) { V5_P1E(0) V5_P1E(2) V5_P1E(4) V5_P1E(6) V5_P1E(8) }
-                    else { V5_MARK("s1rows begin"); V5_P1(0) V5_P1(2) V5_P1(4) V5_P1(6) V5_P1(8) V5_MARK("s1rows end"); }
+                    else { V5_MARK("s1rows begin"); V5_P1(0) V5_STAMP(6); V5_P1(2) V5_STAMP(7); V5_P1(4) V5_STAMP(8); V5_P1(6) V5_STAMP(9); V5_P1(8) V5_STAMP(10); V5_MARK("s1rows end"); }
                     }
 #undef V5_R1
 #undef V5_P1
@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
 #define V5_R2(TT, B) row2(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, sl);
 #define V5_P2(TT) rows2_pair(std::integral_constant<int, BH * PAR + TT>{}, sl);
                         if (border) { V5_R2(0, true) V5_R2(1, true) V5_R2(2, true) V5_R2(3, true) V5_R2(4, true) V5_R2(5, true) V5_R2(6, true) V5_R2(7, true) V5_R2(8, true) V5_R2(9, true) }
-                        else { V5_MARK("s2rows begin"); V5_P2(0) V5_P2(2) V5_P2(4) V5_P2(6) V5_P2(8) V5_MARK("s2rows end"); }
+                        else { V5_MARK("s2rows begin"); V5_P2(0) V5_STAMP(6); V5_P2(2) V5_STAMP(7); V5_P2(4) V5_STAMP(8); V5_P2(6) V5_STAMP(9); V5_P2(8) V5_STAMP(10); V5_MARK("s2rows end"); }
                         }
 #undef V5_R2
 #undef V5_P2

@@ -1,5 +1,6 @@
 // VALU issue rate on gfx950: cycles per wave64 instruction per SIMD for v_fma_f32, v_pk_fma_f32, v_add_f32,
-// v_pk_add_f32 and s_add with 1, 2, 4 waves per SIMD (independent instructions, 8 accumulators).
+// v_pk_add_f32, s_add and (round 4) the DPP, mixed-precision and packed-half instructions of the comb walker with 1, 2, 4
+// waves per SIMD (independent instructions, 8 accumulators).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -20,6 +21,10 @@ __global__ __launch_bounds__(1024) void k(float* out, unsigned long long* cyc, i
                 if (KIND == 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
                 if (KIND == 3) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[i]) : "v"(c2));
                 if (KIND == 4) asm volatile("s_add_i32 %0, %0, 1" : "+s"(s));
+                if (KIND == 5) asm volatile("v_add_f32_dpp %0, %1, %0 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(a[i]) : "v"(a[(i + 4) & 7]));
+                if (KIND == 6) asm volatile("v_fma_mix_f32 %0, %0, %1, 0 op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(m));
+                if (KIND == 7) asm volatile("v_pk_add_f16 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+                if (KIND == 8) asm volatile("v_pk_mul_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(p[i]) : "v"(m2));
             }
     }
     const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -40,4 +45,5 @@ template <int KIND> void run(const char* name) {
                avg / (iters * 32.0 * wps), avg / (iters * 32.0));
     }
 }
-int main() { run<0>("v_fma_f32"); run<1>("v_pk_fma_f32"); run<2>("v_add_f32"); run<3>("v_pk_add_f32"); run<4>("s_add_i32"); return 0; }
+int main() { run<0>("v_fma_f32"); run<1>("v_pk_fma_f32"); run<2>("v_add_f32"); run<3>("v_pk_add_f32"); run<4>("s_add_i32");
+    run<5>("v_add_f32_dpp"); run<6>("v_fma_mix_f32"); run<7>("v_pk_add_f16"); run<8>("v_pk_mul_f32"); return 0; }

@@ -18,7 +18,7 @@ for _ in range(3):
     pipe.run(dl, dr)
 torch.cuda.synchronize()
 L = C.CDLL(os.environ["SMX_LIB_PATH"])
-NW, SW = 8, 6
+NW, SW = 8, 12
 NS = SW * 48
 buf = np.zeros(NW * NS, np.uint64)
 L.smx_debug_read_stamps5(buf.ctypes.data_as(C.c_void_p), buf.size)
@@ -50,3 +50,17 @@ if nit > 8:
     print("SUMMARY phase length W R X (cycles):", " ".join(f"{v:7.0f}" for v in acc), " iteration", f"{acc.sum():7.0f}")
     for ph, nm in enumerate("WRX"):
         print(f"SUMMARY work of phase {nm} per wave:", " ".join(f"{v:6.0f}" for v in accw[ph]))
+
+if nit > 8:
+    # fine stamps of the comb waves: end of each of the five row pairs, relative to the start of the rows (stamp 4)
+    fine = np.zeros((NW, 6)); cnt = 0
+    for it in range(6, nit - 6):
+        r = st[:, it * SW:(it + 1) * SW]
+        if (r[:6, 6:11] > 0).all():
+            fine[:6, :5] += r[:6, 6:11] - r[:6, 4:5]
+            fine[:6, 5] += r[:6, 5] - r[:6, 10]
+            cnt += 1
+    if cnt:
+        fine /= cnt
+        for wv in range(6):
+            print(f"SUMMARY comb wave {wv}: end of row pair 1..5 after the start of the rows:", " ".join(f"{v:6.0f}" for v in fine[wv, :5]), f"  rest of the slot {fine[wv, 5]:6.0f}")
