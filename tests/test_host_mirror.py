@@ -148,7 +148,8 @@ def test_drop_in_main_fast_mode(binary, golden, tmp_path):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags", [["--fused"], ["--host-compare"], ["--fused", "--host-compare"],
-                                   ["--ngpu", "1"], ["--fused", "--pairs", "4"], ["--ngpu", "1", "--pairs", "3"],
+                                   ["--ngpu", "1"], ["--fused", "--pairs", "4"], ["--fused", "--pairs", "5", "--pipeline"],
+                                   ["--ngpu", "1", "--pairs", "3"],
                                    ["--ngpu", "1", "--overlap", "--pairs", "3"]])
 def test_drop_in_main_modes(binary, golden, tmp_path, flags):
     """--fused: one device-resident call after the gray conversion; --host-compare: the reference's
