@@ -316,7 +316,10 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             {
                 const int cl = 64 * (wave - (st2w ? NS1 : 0)) + lane;          // slot in a row of the comb-ordered planes
                 vg = (unsigned)cl * (ST2 ? 4u : 8u);
-                vo = !col_ok ? OOB : (A.qperm ? (unsigned)((L - 1) * comb_rho() + il - 1) * 4u : (unsigned)xo * 4u);
+                // comb-ordered scratch: 8 rho + (i - 1): the eight outputs of a comb are 32 contiguous bytes.  The LAST strip
+                // is stored in column order instead (19 (i - 1) + rho = the local column), so that what lies outside the image is
+                // one contiguous tail of its rows that the WTA pass never reads.
+                vo = !col_ok ? OOB : (A.qperm ? (unsigned)(k + 1 < K ? (L - 1) * comb_rho() + il - 1 : HW * (il - 1) + comb_rho()) * 4u : (unsigned)xo * 4u);
             }
         }
         const f2 ca_i = {rcp_i, (float)(HW * xw)};                       // interior rows: (1/area, area)
@@ -1163,10 +1166,15 @@ __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K
         const int row = (int)(e / OWS), p = (int)(e - (size_t)row * OWS);   // row = k h + y
         const int k = row / h, y = row - k * h;
         const int rho = p / (L - 1), i1 = p - (L - 1) * rho;
-        const int x = OWS * k + HW * i1 + rho;
+        const int x = OWS * k + (k + 1 < K ? HW * i1 + rho : p);        // (the last strip is in column order)
         kp[j] = e < np && x < w ? keys + (size_t)y * w + x : nullptr;
         key[j] = kp[j] ? *kp[j] : KEY_IDENTITY;
     }
+    // nothing of this lane lies in the image (the tail of a row of the last strip): no load at all
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < EPL; ++j) any = any || kp[j];
+    if (!any) return;
     typedef float fv __attribute__((ext_vector_type(EPL)));
     int z = 0;
     constexpr int U = 8;
