@@ -1313,7 +1313,7 @@ size_t v4_workspace_bytes(int w, int h, int nslices) {
     b += 2 * align_up(L.plane * 4, 256);                            // guidance scratch: integrals of I, I*I
     const size_t qp5 = (size_t)v5::strips(w) * h * v5::OWS;          // comb-ordered q plane of the comb walker
     b += (size_t)nslices * align_up((L.plane > qp5 ? L.plane : qp5) * 4, 256);   // q
-    b += align_up((size_t)v5::strips(w) * h * v5::CLP * 12, 256) + 256;          // comb-ordered guidance planes
+    b += align_up((size_t)v5::strips(w) * v5::bands(h) * v5::CLP * 100, 256) + 512;   // comb-ordered guidance planes (80 + 20 B per lane and band)
     const size_t hand5 = v5::sv_hand_floats(h);                    // the comb walker's records (smx_agg_v5.hip)
     b += align_up((size_t)nslices * (L.sv_hand > hand5 ? L.sv_hand : hand5) * 4, 256);
     b += v4_flag_bytes(L, 2 * nslices);                             // control block (shared by both views; K of either walker <= L.K)
@@ -1419,11 +1419,12 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     // comb-ordered guidance planes of the comb walker (smx_agg_v5.h): [K][h][CLP] per view
     v4::f2* g1p[2] = {nullptr, nullptr};
     unsigned* i2p[2] = {nullptr, nullptr};
-    const size_t permn = (size_t)v5::strips(w) * h * v5::CLP;
+    // (band-major, smx_agg_v5.h: 5 NI row pairs of 16 B per lane; per band 16 B + 4 B per lane)
+    const size_t permb = (size_t)v5::strips(w) * v5::bands(h) * v5::CLP;
     if (use_v5)
         for (int v = 0; v < nviews; ++v) {
-            g1p[v] = (v4::f2*)carve(permn * 8);
-            i2p[v] = (unsigned*)carve(permn * 4);
+            g1p[v] = (v4::f2*)carve(permb * 5 * 16);
+            i2p[v] = (unsigned*)carve(permb * 20);
         }
     const char* const fix_end = base;       // image planes + guidance planes: the comb walker addresses them through one descriptor
     for (int i = 0; i < 2 * nviews; ++i) gs[i] = (float*)carve(L.plane * 4);

@@ -31,8 +31,8 @@ struct Args {
     unsigned o_fg[2];     // byte offset of view v's image plane (the other view's is o_fg[v ^ 1])
     // comb-ordered copies (k_v5_perm): what a comb lane cl = 16 rho + il of strip k needs in row y sits at
     // [k][y][cl], so that a wave's guidance load is one contiguous run instead of 16 clusters of 4 columns
-    unsigned o_g1p[2];    // float2 [K][h][CLP]: (mean_I, 1/(var_I + eps)) at the a/b column OWS k - 10 + 19 il + rho
-    unsigned o_i2p[2];    // u32    [K][(h+1)/2][CLP]: image values (fp16) of rows 2 m, 2 m + 1 at the q column OWS k - 19 + 19 il + rho
+    unsigned o_g1p[2];    // float4 [K][5 NI][CLP]: (mean_I, 1/(var_I + eps)) of the a/b rows 2 P - 9, 2 P - 8 (row pair P on the band grid) at the a/b column OWS k - 10 + 19 il + rho
+    unsigned o_i2p[2];    // u32x4 [K][NI][CLP] + u32 [K][NI][CLP] behind it: image values (fp16 pairs) of the ten q rows of band ib at the q column OWS k - 19 + 19 il + rho
     // out, per view: qperm != 0: comb-ordered scratch [slice][K][h][OWS], column OWS k + 19 (il-1) + rho at
     // [(L-1) rho + il - 1] (a wave stores one contiguous run; read back by k_v5_wta); else the caller's [slice][h][w]
     float* q[2];

@@ -281,8 +281,10 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         const rsrc_t r_fix = mk_rsrc(A.fix, A.fix_bytes);
         const int o_fg1 = (int)A.o_fg[view], o_fg2 = (int)A.o_fg[view ^ 1];
         // this strip's rows of the comb-ordered guidance planes
-        const int o_g1p = (int)(A.o_g1p[view] + (unsigned)k * (unsigned)h * (CLP * 8u)),
-                  o_i2p = (int)(A.o_i2p[view] + (unsigned)k * (unsigned)((h + 1) / 2) * (CLP * 4u));
+        // (band-major: 5 NI row pairs of 16 B per lane for stage 1; per band 16 B + 4 B per lane for stage 2 -- smx_agg_v5.h)
+        const int o_g1p = (int)(A.o_g1p[view] + (unsigned)k * (unsigned)(5 * NI) * (CLP * 16u)),
+                  o_i2p = (int)(A.o_i2p[view] + (unsigned)k * (unsigned)NI * (CLP * 16u)),
+                  o_i2b = (int)(A.o_i2p[view] + (unsigned)K * (unsigned)NI * (CLP * 16u) + (unsigned)k * (unsigned)NI * (CLP * 4u));
         const unsigned recb = (unsigned)(NI + 2) * REC_U * 16u;  // bytes per (parity, slice-view)  (smx_agg_v5.h records())
         const rsrc_t r_hand = mk_rsrc(A.hand, (size_t)2 * nsv * recb);
         const int o_in = (int)((((unsigned)(k - 1) & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             rcp_i = rcp_s[HW * xw];
             {
                 const int cl = 64 * (wave - (st2w ? NS1 : 0)) + lane;          // slot in a row of the comb-ordered planes
-                vg = (unsigned)cl * (ST2 ? 4u : 8u);
+                vg = (unsigned)cl * (ST2 ? 4u : 16u);
                 // comb-ordered scratch: 8 rho + (i - 1): the eight outputs of a comb are 32 contiguous bytes.  The LAST strip
                 // is stored in column order instead (19 (i - 1) + rho = the local column), so that what lies outside the image is
                 // one contiguous tail of its rows that the WTA pass never reads.
@@ -391,16 +393,16 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             if (BH * ib + BH <= h) {
 #pragma unroll
                 for (int r = R0; r < R1; ++r) {
-                    cw_ra[r] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a1[r], o_fg1 + (int)bandb, 0);
-                    cw_rb[r] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a2[r], o_fg2 + (int)bandb, 0);
+                    cw_ra[r] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a1[r], o_fg1 + (int)bandb, 0));
+                    cw_rb[r] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a2[r], o_fg2 + (int)bandb, 0));
                 }
             } else {
                 // rows behind the image read the last image row (every load is issued; their cells become -0 in cw_finish)
 #pragma unroll
                 for (int r = R0; r < R1; ++r) {
                     const int yadj = min((int)bandb, (int)ymaxb - (int)cw_rowb[r]);
-                    cw_ra[r] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a1[r] + yadj, o_fg1, 0);
-                    cw_rb[r] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a2[r] + yadj, o_fg2, 0);
+                    cw_ra[r] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a1[r] + yadj, o_fg1, 0));
+                    cw_rb[r] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a2[r] + yadj, o_fg2, 0));
                 }
             }
         };
@@ -468,8 +470,8 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     if (r0 + q < NRQ) {
                         int row, col; bool on;
                         cost_unit(r0 + q, row, col, on);
-                        ra[q] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(row, col, 0), o_fg1, 0);
-                        rb[q] = __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(row, col, d), o_fg2, 0);
+                        ra[q] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(row, col, 0), o_fg1, 0));
+                        rb[q] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(row, col, d), o_fg2, 0));
                     }
                 }
 #pragma unroll
@@ -491,23 +493,28 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 }
             }
         };
-        // guidance of the output rows of iteration ib (rows clamped into the image: every load is issued)
+        // guidance of the output rows of iteration ib: FEW, WIDE loads -- a vector-memory instruction costs its wave and the CU's
+        // address path the same whatever its width, and ten 8-byte loads per stage-1 wave and band were 700-1000 cycles of its
+        // slot.  Stage 1: five 16-byte loads of two rows each (the planes hold row pairs on the band grid: pair P = rows
+        // 2 P - 9, 2 P - 8).  Stage 2: the five fp16 row pairs of the band as one 16-byte and one 4-byte load.
         auto issue_guid = [&](int ib, int yq0) {
             if (WHATIF & 32) return;
+            const int ibc = __builtin_amdgcn_readfirstlane(min(max(ib, 0), NI - 1));
             if constexpr (ROLE == ROLE_S1) {
+                static_assert(BH == 10, "five row pairs per band");
 #pragma unroll
-                for (int t = 0; t < BH; ++t) {
-                    const int y = min(max(BH * ib - R + t, 0), h - 1);
-                    const u2 g = __builtin_amdgcn_raw_buffer_load_b64(r_fix, (int)vg, o_g1p + y * (CLP * 8), 0);
-                    gq[t] = __builtin_bit_cast(f2, g);
+                for (int j = 0; j < BH / 2; ++j) {
+                    // (bit_cast of the whole vector: taking .y/.z/.w of the builtin's result through a u4 copy let the compiler narrow the
+                    // load to ONE dword here -- wrong results, found by bisection)
+                    const f4 g = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)vg, o_g1p + (5 * ibc + j) * (CLP * 16), 0));
+                    gq[2 * j] = (f2){g.x, g.y};
+                    gq[2 * j + 1] = (f2){g.z, g.w};
                 }
             } else if constexpr (ST2) {
-                // q rows yq0 + 2 m, + 1: yq0 is even, so a pair is one element of the row-pair plane
-#pragma unroll
-                for (int m = 0; m < BH / 2; ++m) {
-                    const int yp = min(max(yq0 / 2 + m, 0), (h - 1) / 2);
-                    gI[m] = ldu(r_fix, vg, o_i2p + yp * (CLP * 4));
-                }
+                // (yq0 = 10 (ib - 1) - 18 at every call site: the band grid of the planes)
+                const u4 a = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)(vg * 4u), o_i2p + ibc * (CLP * 16), 0));
+                gI[0] = a.x; gI[1] = a.y; gI[2] = a.z; gI[3] = a.w;
+                gI[4] = ldu(r_fix, vg, o_i2b + ibc * (CLP * 4));
             }
         };
 
@@ -1022,6 +1029,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
 #undef V5_P1
 #undef V5_P1E
                     issue_guid(sl + 1, 0);
+                    V5_STAMP(11);
                 }
             } else {
                 if (sl >= 0) {
@@ -1119,24 +1127,43 @@ struct PermArgs {
     f2* g1p[2];
     unsigned* i2p[2];
 };
-__global__ __launch_bounds__(CLP) void k_v5_perm(PermArgs pa, int w, int h) {
+__global__ __launch_bounds__(CLP) void k_v5_perm(PermArgs pa, int w, int h, int K, int NI) {
     const int cl = threadIdx.x, cw = cl >> 6, ln = cl & 63;
     const int rho = ln / L < CPW ? CPW * cw + ln / L : HW, il = ln % L;
-    const int k = blockIdx.x / h, y = blockIdx.x - k * h, v = blockIdx.y;
+    const int k = blockIdx.x / NI, ib = blockIdx.x - k * NI, v = blockIdx.y;
     const int x1 = OWS * k - R - 1 + HW * il + rho;     // a/b column of stage-1 comb lane cl
     const int xq = x1 - R;                              // q column of stage-2 comb lane cl
-    f2 g = {0.0f, 0.0f};
-    if (rho < HW && x1 >= 0 && x1 < w) g = pa.G[v][(size_t)y * w + x1];
-    pa.g1p[v][((size_t)k * h + y) * CLP + cl] = g;
-    if ((y & 1) == 0) {
-        // image values of rows y, y + 1 as one fp16 pair
-        fg_t pr = {(_Float16)0.0f, (_Float16)0.0f};
-        if (rho < HW && xq >= 0 && xq < w) {
-            pr.x = pa.FG[v][(size_t)y * (w + 2 * PADX) + PADX + xq].x;
-            if (y + 1 < h) pr.y = pa.FG[v][(size_t)(y + 1) * (w + 2 * PADX) + PADX + xq].x;
+    const bool on1 = rho < HW && x1 >= 0 && x1 < w, on2 = rho < HW && xq >= 0 && xq < w;
+    // stage 1: the a/b rows 10 ib - 9 + t of band ib as five row pairs (rows clamped into the image; the a_k, b_k of rows
+    // outside it are replaced by -0 whatever their guidance)
+    f4* const g1 = (f4*)pa.g1p[v];
+#pragma unroll
+    for (int j = 0; j < BH / 2; ++j) {
+        const int ya = min(max(BH * ib - R + 2 * j, 0), h - 1), yb = min(max(BH * ib - R + 2 * j + 1, 0), h - 1);
+        f4 g = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (on1) {
+            const f2 a = pa.G[v][(size_t)ya * w + x1], b = pa.G[v][(size_t)yb * w + x1];
+            g = (f4){a.x, a.y, b.x, b.y};
         }
-        pa.i2p[v][((size_t)k * ((h + 1) / 2) + y / 2) * CLP + cl] = __builtin_bit_cast(unsigned, pr);
+        g1[((size_t)k * (5 * NI) + 5 * ib + j) * CLP + cl] = g;
     }
+    // stage 2: the q rows 10 (ib - 1) - 18 + 2 m, + 1 of band ib: image values as fp16 pairs (row pairs clamped like the
+    // loads they replace; a row behind the image holds 0)
+    unsigned pr[BH / 2];
+#pragma unroll
+    for (int m = 0; m < BH / 2; ++m) {
+        const int yp = min(max((BH * (ib - 1) - 2 * R) / 2 + m, 0), (h - 1) / 2), y = 2 * yp;
+        fg_t p2 = {(_Float16)0.0f, (_Float16)0.0f};
+        if (on2) {
+            p2.x = pa.FG[v][(size_t)y * (w + 2 * PADX) + PADX + xq].x;
+            if (y + 1 < h) p2.y = pa.FG[v][(size_t)(y + 1) * (w + 2 * PADX) + PADX + xq].x;
+        }
+        pr[m] = __builtin_bit_cast(unsigned, p2);
+    }
+    u4* const i2a = (u4*)pa.i2p[v];
+    unsigned* const i2b = pa.i2p[v] + (size_t)K * NI * CLP * 4;
+    i2a[((size_t)k * NI + ib) * CLP + cl] = (u4){pr[0], pr[1], pr[2], pr[3]};
+    i2b[((size_t)k * NI + ib) * CLP + cl] = pr[4];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1210,7 +1237,8 @@ int v5_perm_launch(int nviews, const aggdev::f2* const* G, const aggdev::fg_t* c
     v5::PermArgs pa;
     memset(&pa, 0, sizeof(pa));
     for (int v = 0; v < nviews; ++v) { pa.G[v] = G[v]; pa.FG[v] = FG[v]; pa.g1p[v] = g1p[v]; pa.i2p[v] = i2p[v]; }
-    hipLaunchKernelGGL(v5::k_v5_perm, dim3((unsigned)(v5::strips(w) * h), (unsigned)nviews), dim3(v5::CLP), 0, st, pa, w, h);
+    const int K = v5::strips(w), NI = v5::bands(h);
+    hipLaunchKernelGGL(v5::k_v5_perm, dim3((unsigned)(K * NI), (unsigned)nviews), dim3(v5::CLP), 0, st, pa, w, h, K, NI);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

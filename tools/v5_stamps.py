@@ -64,3 +64,9 @@ if nit > 8:
         fine /= cnt
         for wv in range(6):
             print(f"SUMMARY comb wave {wv}: end of row pair 1..5 after the start of the rows:", " ".join(f"{v:6.0f}" for v in fine[wv, :5]), f"  rest of the slot {fine[wv, 5]:6.0f}")
+
+if nit > 8:
+    print("stage-1 wave 0, slots 8..19: rows end -> guidance issued (stamp 11) -> end of the slot function (stamp 5) -> next slot starts; cycles")
+    for it in range(8, min(20, nit - 1)):
+        r = st[0, it * SW:(it + 1) * SW]; nx = st[0, (it + 1) * SW]
+        print(f"  slot {it:2d}: guid {r[11]-r[10]:5d}  tail {r[5]-r[11]:5d}  barrier {nx-r[5]:5d}   (slot {nx - r[0]:5d})")
