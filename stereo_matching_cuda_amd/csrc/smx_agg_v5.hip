@@ -1175,7 +1175,7 @@ struct Wta5Args {
     const float* q[2];
     int64_t* keys[2];
 };
-// EPL = elements per lane: 2 (8-byte loads; needs an even strip row OWS... the rows are OWS = 209 floats, so pairs
+// EPL = elements per lane: 4 (16-byte loads), 2 (8-byte loads; needs an even strip row OWS... the rows are OWS = 209 floats, so pairs
 // are taken over the whole plane: K h OWS even and 8-byte aligned planes) or 1
 template <int EPL>
 __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K, int count, int slice0) {
@@ -1251,7 +1251,12 @@ int v5_wta_launch(int nviews, const float* const* q, int64_t* const* keys, int w
     const size_t np = (size_t)K * h * v5::OWS;
     bool al8 = np % 2 == 0;
     for (int v = 0; v < nviews; ++v) al8 = al8 && ((uintptr_t)wa.q[v] & 7) == 0;
-    if (al8)
+    bool al16 = np % 4 == 0;        // 16-byte loads (four elements per lane) where the planes allow
+    for (int v = 0; v < nviews; ++v) al16 = al16 && ((uintptr_t)wa.q[v] & 15) == 0;
+    if (al16)
+        hipLaunchKernelGGL(v5::k_v5_wta<4>, dim3((unsigned)((np / 4 + 255) / 256), (unsigned)nviews), dim3(256), 0, st, wa, w, h,
+                           K, count, slice0);
+    else if (al8)
         hipLaunchKernelGGL(v5::k_v5_wta<2>, dim3((unsigned)((np / 2 + 255) / 256), (unsigned)nviews), dim3(256), 0, st, wa, w, h,
                            K, count, slice0);
     else
