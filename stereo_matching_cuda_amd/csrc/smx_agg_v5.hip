@@ -1041,8 +1041,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
 #pragma unroll
                     for (int t = 0; t < BH; ++t) r2[t] = tile_rd(t2 + t * RS + jt);
                     const int hq = hu_idx();
-                    if (succ && hq >= 0 && hq < REC_U) {
-                        f4 hov;
+                    const bool rec_out = succ && hq >= 0 && hq < REC_U;
+                    f4 hov = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (rec_out) {
                         if (hq < NHU) {
                             const int t = hq / 10, j = (hq - 10 * t) * 2;
                             const float* p = t2 + t * RS + OWS + j;
@@ -1051,11 +1052,13 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                             const float* p = T1(sl) + 2 * (hq - NHU) * RS + OWS - 1;
                             hov = (f4){p[0], p[P1], p[RS], p[RS + P1]};
                         }
-                        st16_sc1(r_hand, (unsigned)(o_out + sl * REC_U * 16) + (unsigned)hq * 16u, hov);
                     }
+                    // everything this wave needs from tile 2 is in registers: tell the stage-1 waves at once (they are waiting to
+                    // overwrite the tile); the record goes to memory behind that
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r2[0]), "+v"(r2[1]), "+v"(r2[2]), "+v"(r2[3]), "+v"(r2[4]), "+v"(r2[5]),
-                                 "+v"(r2[6]), "+v"(r2[7]), "+v"(r2[8]), "+v"(r2[9]) :: "memory");
+                                 "+v"(r2[6]), "+v"(r2[7]), "+v"(r2[8]), "+v"(r2[9]), "+v"(hov) :: "memory");
                     if (lane == 0) __hip_atomic_fetch_add(&s_x1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (rec_out) st16_sc1(r_hand, (unsigned)(o_out + sl * REC_U * 16) + (unsigned)hq * 16u, hov);
                     V5_MARK("s2head end");
                     V5_STAMP(3);
                     V5_STAMP(4);
