@@ -112,6 +112,15 @@ constexpr int WHATIF = SMX_V5_WHATIF;
 #define SMX_V5_WMAP 0
 #endif
 constexpr int WMAP = SMX_V5_WMAP;
+// Wave priorities of the roles while they work (the row-scan wave runs at 3): a slot ends with its slowest wave, and the
+// stage-2 comb waves have a quarter of a slot to spare -- measured: cost 2 / stage 1 1 / stage 2 0 is 3.7 % faster than all 0
+#ifndef SMX_V5_PRIO_COST
+#define SMX_V5_PRIO_COST 2
+#endif
+#ifndef SMX_V5_PRIO_S1
+#define SMX_V5_PRIO_S1 1
+#endif
+constexpr int PRIO_COST = SMX_V5_PRIO_COST, PRIO_S1 = SMX_V5_PRIO_S1;
 
 #ifdef SMX_V5_DUMP
 // Diagnostic build only: tile 1 (current buffer), tile 2 and the comb registers of one item behind the barrier that
@@ -231,7 +240,8 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     const int lane = threadIdx.x & 63;
     const int hwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // role of a hardware wave (waves w and w + 4 of a workgroup share a SIMD)
-    const int wave = PIPE && WMAP == 1 ? (int)((0x75436210u >> (4 * hwave)) & 7u) : PIPE && WMAP == 2 ? (int)((0x54317620u >> (4 * hwave)) & 7u) : hwave;
+    const int wave = PIPE && WMAP == 1 ? (int)((0x75436210u >> (4 * hwave)) & 7u) : PIPE && WMAP == 2 ? (int)((0x54317620u >> (4 * hwave)) & 7u)
+                     : PIPE && WMAP == 3 ? (int)((0x53764210u >> (4 * hwave)) & 7u) : PIPE && WMAP == 4 ? (int)((0x57436210u >> (4 * hwave)) & 7u) : hwave;
     const int tid = 64 * wave + lane;
     const int w = A.w, h = A.h, K = A.K, NI = A.NI, nsv = A.nsv;
     const CostConst cc = A.cc;
@@ -1002,7 +1012,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     if (sl == NI - 1)
                         s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                __builtin_amdgcn_s_setprio(PRIO_COST);
                 if (!(WHATIF & 2) && sl + 2 < NI) eval_band_p(sl + 2, T1(sl + 2));
+                __builtin_amdgcn_s_setprio(0);
             } else if constexpr (ROLE == ROLE_S1) {
                 // the record of pass sl+1 is needed at the end of this slot: its load goes out now (unconditionally);
                 // what it returns counts only if the record had been published
@@ -1012,6 +1024,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     f2 rv = tile_rd(t1 + jt);
                     tile2 = T2(sl);
                     V5_STAMP(3);
+                    __builtin_amdgcn_s_setprio(PRIO_S1);
                     x1_need = (unsigned)NS1 * (unsigned)(sl + 1);
                     const bool border = BH * sl - R < R + 1 || BH * sl - R + BH - 1 > h - 1 - R;
                     if (border || (WHATIF & 4)) wait_x1();      // (the interior rows wait in front of their first store)
@@ -1028,6 +1041,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
 #undef V5_R1
 #undef V5_P1
 #undef V5_P1E
+#ifndef SMX_V5_PRIO_S1TAIL
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                     issue_guid(sl + 1, 0);
                     V5_STAMP(11);
                 }
@@ -1036,6 +1052,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     if (succ && tid == 64 * 2 * NS1 - 1 && sl >= 1) flag_store(myflag, (unsigned)sl);
                     // the a/b band sl-2 (scanned in pass sl-1) out of its tile; the record of pass sl-1 (index sl): halo of that
                     // band, carries of stage-1 band sl
+                    __builtin_amdgcn_s_setprio(3);      // (the stage-1 waves are waiting for this copy-out)
                     V5_MARK("s2head begin");
                     const float* const t2 = T2(sl);
 #pragma unroll
@@ -1060,6 +1077,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     if (lane == 0) __hip_atomic_fetch_add(&s_x1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     if (rec_out) st16_sc1(r_hand, (unsigned)(o_out + sl * REC_U * 16) + (unsigned)hq * 16u, hov);
                     V5_MARK("s2head end");
+                    __builtin_amdgcn_s_setprio(0);
                     V5_STAMP(3);
                     V5_STAMP(4);
                     if (sl >= 2) {
@@ -1093,6 +1111,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 V5_MARK("s1handin begin");
                 if (pred && sl + 2 < NI) { cin1 = CI(sl + 1); tile2 = T2(sl); hand_in(sl >= 0); }
                 V5_MARK("s1handin end");
+#ifdef SMX_V5_PRIO_S1TAIL
+                __builtin_amdgcn_s_setprio(0);
+#endif
             }
             V5_STAMP(5);
         };
