@@ -46,6 +46,7 @@ struct Args {
     unsigned* status;     // != 0: a flag wait timed out (results invalid)
     CostConst cc;
     unsigned th2;        // (th_color, th_grad) as packed halves (exact: v5_supported)
+    int prio;            // 1: role priorities for the cost and stage-1 waves (smx_agg_v5.hip PRIO_*): small and medium launches
     int fast;            // 1: FAST mode (reciprocal multiplication instead of the exact division; not bit-exact)
 };
 

@@ -112,8 +112,10 @@ constexpr int WHATIF = SMX_V5_WHATIF;
 #define SMX_V5_WMAP 0
 #endif
 constexpr int WMAP = SMX_V5_WMAP;
-// Wave priorities of the roles while they work (the row-scan wave runs at 3): a slot ends with its slowest wave, and the
-// stage-2 comb waves have a quarter of a slot to spare -- measured: cost 2 / stage 1 1 / stage 2 0 is 3.7 % faster than all 0
+// Wave priorities of the roles while they work (the row-scan wave runs at 3, the stage-2 waves' copy-out too): a slot ends
+// with its slowest wave, and the stage-2 comb waves have a quarter of a slot to spare -- measured: cost 2 / stage 1 1 /
+// stage 2 0 is 4 % faster than all 0 on KITTI shape and 1-2 % on shapes up to 4 Mpix x 128 disparities, but 3-4 % SLOWER on
+// Motorcycle and 4K (Args::prio: the host switches them by the size of the launch)
 #ifndef SMX_V5_PRIO_COST
 #define SMX_V5_PRIO_COST 2
 #endif
@@ -1012,7 +1014,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     if (sl == NI - 1)
                         s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                __builtin_amdgcn_s_setprio(PRIO_COST);
+                if (A.prio) __builtin_amdgcn_s_setprio(PRIO_COST);
                 if (!(WHATIF & 2) && sl + 2 < NI) eval_band_p(sl + 2, T1(sl + 2));
                 __builtin_amdgcn_s_setprio(0);
             } else if constexpr (ROLE == ROLE_S1) {
@@ -1024,7 +1026,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     f2 rv = tile_rd(t1 + jt);
                     tile2 = T2(sl);
                     V5_STAMP(3);
-                    __builtin_amdgcn_s_setprio(PRIO_S1);
+                    if (A.prio) __builtin_amdgcn_s_setprio(PRIO_S1);
                     x1_need = (unsigned)NS1 * (unsigned)(sl + 1);
                     const bool border = BH * sl - R < R + 1 || BH * sl - R + BH - 1 > h - 1 - R;
                     if (border || (WHATIF & 4)) wait_x1();      // (the interior rows wait in front of their first store)

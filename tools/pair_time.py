@@ -1,5 +1,5 @@
 """ms per KITTI-shape pair of the device-resident pipeline without any event in the loop (dev tool, GPU box):
-python tools/pair_time.py [path] [repeats]   -- SMX_LIB_PATH + SMX_ALLOW_LIB_OVERRIDE=1 select a variant build"""
+python tools/pair_time.py [path] [repeats] [workload]   -- SMX_LIB_PATH + SMX_ALLOW_LIB_OVERRIDE=1 select a variant build"""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -8,20 +8,26 @@ from stereo_matching_cuda_amd import synth
 from stereo_matching_cuda_amd.device import PairPipeline
 path = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-w, h, D = synth.SHAPES["kitti"]
-Il, Ir = synth.gen_pair(w, h, D, 20150101)
+wl = sys.argv[3] if len(sys.argv) > 3 else "kitti"
+import os
+if "," in wl:                                   # "w,h,D": an ad-hoc shape
+    w, h, D = (int(v) for v in wl.split(","))
+else:
+    w, h, D = synth.SHAPES[wl]
+Il, Ir = synth.gen_pair(w, h, D, synth.SEEDS.get(wl, 1))
+N = max(10, int(300 * (1242 * 375 * 192) / (float(w) * h * D)))
 pipe = PairPipeline(w, h, D)
 dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
 smx.check(smx.lib().smx_set_agg_path(path))
 def step():
     pipe.init_keys(); pipe.aggregate_pair(dl, dr); pipe.finish()
-for _ in range(300): step()
+for _ in range(N): step()
 torch.cuda.synchronize()
 out = []
 for _ in range(reps):
     t0 = time.perf_counter()
-    for _ in range(300): step()
+    for _ in range(N): step()
     torch.cuda.synchronize()
-    out.append((time.perf_counter() - t0) / 300 * 1e3)
+    out.append((time.perf_counter() - t0) / N * 1e3)
 pipe.check_status()
-print("path", path, "ms/pair", " ".join(f"{v:.4f}" for v in out), flush=True)
+print(wl, "path", path, "ms/pair", " ".join(f"{v:.4f}" for v in out), flush=True)
