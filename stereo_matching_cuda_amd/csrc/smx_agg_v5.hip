@@ -115,14 +115,20 @@ constexpr int WMAP = SMX_V5_WMAP;
 // Wave priorities of the roles while they work (the row-scan wave runs at 3, the stage-2 waves' copy-out too): a slot ends
 // with its slowest wave, and the stage-2 comb waves have a quarter of a slot to spare -- measured: cost 2 / stage 1 1 /
 // stage 2 0 is 4 % faster than all 0 on KITTI shape and 1-2 % on shapes up to 4 Mpix x 128 disparities, but 3-4 % SLOWER on
-// Motorcycle and 4K (Args::prio: the host switches them by the size of the launch)
+// Motorcycle and 4K, where no priority at all is best (Args::prio: the host switches the whole set by the size of the launch)
 #ifndef SMX_V5_PRIO_COST
 #define SMX_V5_PRIO_COST 2
 #endif
 #ifndef SMX_V5_PRIO_S1
 #define SMX_V5_PRIO_S1 1
 #endif
-constexpr int PRIO_COST = SMX_V5_PRIO_COST, PRIO_S1 = SMX_V5_PRIO_S1;
+#ifndef SMX_V5_PRIO_S2HEAD
+#define SMX_V5_PRIO_S2HEAD 3
+#endif
+#ifndef SMX_V5_PRIO_SCAN
+#define SMX_V5_PRIO_SCAN 3
+#endif
+constexpr int PRIO_COST = SMX_V5_PRIO_COST, PRIO_S1 = SMX_V5_PRIO_S1, PRIO_S2HEAD = SMX_V5_PRIO_S2HEAD, PRIO_SCAN = SMX_V5_PRIO_SCAN;
 
 #ifdef SMX_V5_DUMP
 // Diagnostic build only: tile 1 (current buffer), tile 2 and the comb registers of one item behind the barrier that
@@ -842,7 +848,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             V5_STAMP(0);
             if constexpr (!ST2) {
                 if (wave == 0) {
-                    if (!(WHATIF & 1024)) __builtin_amdgcn_s_setprio(3);
+                    if (!(WHATIF & 1024) && A.prio) __builtin_amdgcn_s_setprio(PRIO_SCAN);
                     if (!(WHATIF & 1)) rowscans(i, i - 1, t1, tile2, cin1);
                     __builtin_amdgcn_s_setprio(0);
                 } else if (!(WHATIF & 2)) {
@@ -1001,7 +1007,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             // before the barrier above and not touched during this slot; flags only grow, so a stale entry is harmless
             seen = max(seen, s_peek[sl & 1]);
             if constexpr (ROLE == ROLE_SCAN) {
-                if (!(WHATIF & 1024)) __builtin_amdgcn_s_setprio(3);
+                if (!(WHATIF & 1024) && A.prio) __builtin_amdgcn_s_setprio(PRIO_SCAN);
                 V5_MARK("scan begin");
                 if (!(WHATIF & 1) && sl + 1 < NI) rowscans(sl + 1, sl - 1, T1(sl + 1), T2(sl - 1), CI(sl));
                 V5_MARK("scan end");
@@ -1054,7 +1060,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     if (succ && tid == 64 * 2 * NS1 - 1 && sl >= 1) flag_store(myflag, (unsigned)sl);
                     // the a/b band sl-2 (scanned in pass sl-1) out of its tile; the record of pass sl-1 (index sl): halo of that
                     // band, carries of stage-1 band sl
-                    __builtin_amdgcn_s_setprio(3);      // (the stage-1 waves are waiting for this copy-out)
+                    if (A.prio) __builtin_amdgcn_s_setprio(PRIO_S2HEAD);      // (the stage-1 waves are waiting for this copy-out)
                     V5_MARK("s2head begin");
                     const float* const t2 = T2(sl);
 #pragma unroll
