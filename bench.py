@@ -115,11 +115,18 @@ def main():
     # than the power controller's ramp), then the W warmup steps of the contract
     preheat = 0
     tp = time.perf_counter()
-    while time.perf_counter() - tp < args.preheat_s:
-        for _ in range(10):
+    if world > 1:
+        # every rank must run the SAME number of steps (each step has a collective in it): a fixed count, not a clock
+        for _ in range(200 if args.preheat_s > 0 else 0):
             step()
         torch.cuda.synchronize(device)
-        preheat += 10
+        preheat = 200 if args.preheat_s > 0 else 0
+    else:
+        while time.perf_counter() - tp < args.preheat_s:
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize(device)
+            preheat += 10
     for _ in range(args.warmup):
         step()
     fence()
