@@ -214,8 +214,10 @@ int smx_dev_agg_status(const void* d_workspace);
  *       (smx_agg_v4.hip: any radius <= 9, materialised cost volumes)
  *   1 = force multi-kernel            2 = force fused (error if radius > 9), walker chosen as in auto
  *   3 = fused, ring walker forced     5 = fused, comb walker forced (error where it does not apply)
- *   4 = FAST: the ring walker with wave-parallel row scans -- the additions of the row prefix sums are
- *       re-associated, so the results are NOT bit-exact; reported separately, never a default.
+ *   4 = FAST, NOT bit-exact; reported separately, never a default.  Where the comb walker applies: the same sums in the
+ *       same order, window means by multiplication with the rounded reciprocal of the area instead of the exact division
+ *       (aggregated costs within ~2.4e-4 relative).  Elsewhere: the ring walker with wave-parallel, re-associated row
+ *       prefix sums (within ~4e-3).
  * smx_last_agg_path() reports what the last aggregation on this thread ran: 1 multi-kernel, 2 ring walker,
  * 4 FAST, 5 comb walker. */
 int smx_set_agg_path(int path);
