@@ -222,6 +222,14 @@ int smx_dev_agg_status(const void* d_workspace);
  * 4 FAST, 5 comb walker. */
 int smx_set_agg_path(int path);
 int smx_last_agg_path(void);
+/* Slices per launch of the fused aggregation.  The reference's slice loop (guidedFilter.cu:171-238) handles ONE slice per
+ * iteration; the fused walker handles as many per launch as the caller's workspace holds, and accumulates the running WTA
+ * across launches.  smx_set_max_slices_per_launch(n > 0) bounds that number for the calling thread's calls whatever the
+ * workspace holds (0 = no bound, the default) -- the knob behind `slices_in_flight` of the Python pipeline and bench.py.
+ * smx_last_agg_chunk reports what the calling thread's last fused aggregation did: slices per walker launch (of the first,
+ * i.e. largest, launch) and the number of walker launches. */
+int smx_set_max_slices_per_launch(int n);
+int smx_last_agg_chunk(int* slices_per_launch, int* walker_launches);
 /* Tile geometry of the fused aggregation for a box radius: output columns per strip, rows per band,
  * columns computed per strip (strip_cols + 2*radius + 1).  For tests that aim at tile boundaries. */
 int smx_agg_geometry(int radius, int* strip_cols, int* band_rows, int* tile_cols);

@@ -94,6 +94,8 @@ SIGNATURES = {
     "smx_unpack_key": (None, [_i64, C.POINTER(_f), C.POINTER(_u32)]),
     "smx_set_agg_path": (_i, [_i]),
     "smx_last_agg_path": (_i, []),
+    "smx_set_max_slices_per_launch": (_i, [_i]),
+    "smx_last_agg_chunk": (_i, [C.POINTER(_i), C.POINTER(_i)]),
     "smx_agg_geometry": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "smx_set_timing": (_i, [_i]),
     "smx_last_agg_ms": (_i, [C.POINTER(_f), C.POINTER(_i)]),

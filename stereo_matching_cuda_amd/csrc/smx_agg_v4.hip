@@ -1326,10 +1326,8 @@ static int launch_walk4(const v4::Args& a, hipStream_t st) {
     SMX_HIP(hipGetDevice(&dev));
     SMX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     int per_cu = v4::WG_PER_CU;                          // persistent: WG_PER_CU workgroups per CU
-    if (const char* e = getenv("SMX_V4_WG_PER_CU")) {    // experiments: fewer workgroups per CU
-        const int v = atoi(e);
-        if (v >= 1 && v <= v4::WG_PER_CU) per_cu = v;
-    }
+    static const int env_per_cu = env_int_once("SMX_V4_WG_PER_CU", 0);   // experiments: fewer workgroups per CU
+    if (env_per_cu >= 1 && env_per_cu <= v4::WG_PER_CU) per_cu = env_per_cu;
     const int slots = per_cu * ncu;
     const int grid = a.nitems < slots ? a.nitems : slots;
     if (a.R == v4::RMAX)
@@ -1369,6 +1367,14 @@ int v4_read_status(const void* d_ws, unsigned* out) {
     return SMX_OK;
 }
 
+// Bytes of the region the comb walker addresses through its one 32-bit-offset descriptor: both image planes, the
+// guidance planes of the views and their comb-ordered copies (the carving order of aggregate_v4)
+size_t v5_fix_bytes(int w, int h, int nviews) {
+    const V4Layout L = v4_layout(w, h, v4::RMAX);
+    const size_t permb = (size_t)v5::strips(w) * v5::bands(h) * v5::CLP;
+    return 2 * align_up(L.fg * 4, 256) + (size_t)nviews * (align_up(L.plane * 8, 256) + align_up(permb * 5 * 16, 256) + align_up(permb * 20, 256));
+}
+
 // Aggregation + WTA of slices [s_begin, s_end) of `nviews` (1 or 2) views.  View v uses d_guide[v]
 // as guidance; its cost slices are d_cost[v] (materialised, slice s at (s - s_begin)*w*h) or, when
 // d_cost[v] == NULL, are built on the fly against d_guide[v ^ 1] (nviews == 2) / d_other[0].
@@ -1376,16 +1382,23 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                  const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
                  const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
                  uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
-                 hipStream_t st, int* launches, bool fast, int walker, int* walker_used) {
+                 hipStream_t st, const AggOpts& opt, AggInfo* info) {
     const int R = p->radius;
+    const bool fast = opt.fast;
     V4Layout L = v4_layout(w, h, R);
     const bool use_cost = d_cost && d_cost[0];
     // The comb walker (smx_agg_v5.hip) serves the hot case: radius 9, costs built from the images, exact mode.
-    // walker: 0 = choose, 4 = the ring walker of this file.  Both share this orchestration: image planes, guidance
+    // opt.walker: 0 = choose, 4 = the ring walker of this file.  Both share this orchestration: image planes, guidance
     // statistics, chunking, WTA pass; only the strip / band geometry and the records differ.
-    const bool use_v5 = walker != 4 && !use_cost && v5_supported(p) &&
-                        (size_t)h * ((size_t)w + 2 * v4::PADX) * 24 < 0x80000000ull;   // (its planes share one 32-bit-offset descriptor)
-    if (walker_used) *walker_used = use_v5 ? 5 : 4;
+    // The comb walker addresses both image planes, the guidance planes and their comb-ordered copies through ONE buffer
+    // descriptor with 32-bit offsets, 0x80000000 marking "outside": the whole region must stay below 2 GiB
+    // (v5_fix_bytes: the same terms the carving below uses).
+    const bool v5_fits = v5_fix_bytes(w, h, nviews) < 0x80000000ull;
+    const bool use_v5 = opt.walker != 4 && !use_cost && v5_supported(p) && v5_fits;
+    if (opt.walker == 5 && !use_v5)
+        return fail(SMX_E_ARG, "aggregate_v4: the comb walker does not apply (radius 9, costs built from the images, default-like "
+                               "cost parameters, planes of %d x %d within its 2 GiB descriptor: %s)", w, h, v5_fits ? "yes" : "no");
+    if (info) { *info = AggInfo(); info->walker_used = use_v5 ? 5 : 4; }
     if (use_v5) {
         L.K = v5::strips(w);
         L.NI = v5::bands(h);
@@ -1427,6 +1440,8 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             i2p[v] = (unsigned*)carve(permb * 20);
         }
     const char* const fix_end = base;       // image planes + guidance planes: the comb walker addresses them through one descriptor
+    if (use_v5 && (size_t)(fix_end - (const char*)FG[0]) >= 0x80000000ull)
+        return fail(SMX_E_ARG, "aggregate_v4: comb walker planes exceed the 2 GiB descriptor (v5_fix_bytes out of step with the carving)");
     for (int i = 0; i < 2 * nviews; ++i) gs[i] = (float*)carve(L.plane * 4);
     const int total = s_end - s_begin;
     // per slice-view: q plane (unless the caller's volume is written directly) + records + flags
@@ -1440,7 +1455,9 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         return fail(SMX_E_WS, "aggregate_v4: workspace %zu B too small (need >= %zu B per view)",
                     ws_bytes, v4_workspace_bytes(w, h, 1));
     int chunk = fit > (size_t)total ? total : (int)fit;
+    if (opt.max_chunk > 0 && chunk > opt.max_chunk) chunk = opt.max_chunk;
     if (chunk < 1) chunk = 1;
+    if (info) info->chunk = chunk;
     const int nsv_max = chunk * nviews;
     float* qbuf[2] = {nullptr, nullptr};
     if (own_q)
@@ -1480,8 +1497,8 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             rows = rows > v4::GR_MAXROWS ? v4::GR_MAXROWS : rows;
             rows = rows < 1 && (size_t)8 * wpad <= (size_t)(152 * 1024) ? 1 : rows;
             if (rows < 1) return fail(SMX_E_ARG, "aggregate_v4: image too wide for the guidance row scan");
-            // (per device, so not cached in a static: the sharded driver runs several devices from one process)
-            SMX_HIP(hipFuncSetAttribute((const void*)v4::k_v4_guid_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            static LdsLimitOnce lim;     // (once per device: the sharded driver runs several devices from one process)
+            SMX_HIP(lim.ensure((const void*)v4::k_v4_guid_rows, 160 * 1024));
             hipLaunchKernelGGL(v4::k_v4_guid_rows, dim3(cdivu4(h, rows), nviews), dim3(v4::GR_NT), (size_t)8 * rows * wpad, st,
                                ga, w, h, rows);
         }
@@ -1554,7 +1571,8 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                 // +1-2 %; Motorcycle / 4K -3-4 %): switched by the cells of the launch
                 const double cells = (double)a.nsv * (double)w * (double)h;
                 b.prio = cells < 1.5e9 ? 1 : 0;
-                if (const char* e = getenv("SMX_V5_PRIO")) b.prio = atoi(e) != 0;
+                static const int env_prio = env_int_once("SMX_V5_PRIO", -1);     // (A/B runs)
+                if (env_prio >= 0) b.prio = env_prio != 0;
             }
             b.qperm = own_q ? 1 : 0;
             b.q_plane = qplane;
@@ -1562,6 +1580,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         } else if (fast) rc = use_cost ? launch_walk4<v4::SRC_COST, true>(a, st) : launch_walk4<v4::SRC_IMG, true>(a, st);
         else rc = use_cost ? launch_walk4<v4::SRC_COST, false>(a, st) : launch_walk4<v4::SRC_IMG, false>(a, st);
         if (rc) return rc;
+        if (info) ++info->walker_launches;
         stage_mark(ST_WALK, st);
         bool al8 = L.plane % 2 == 0;
         for (int v = 0; v < nviews; ++v) al8 = al8 && ((uintptr_t)wa.q[v] & 7) == 0;
@@ -1577,7 +1596,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         stage_mark(ST_WTA, st);
         nl += s0 != s_begin ? 3 : 2;
     }
-    if (launches) *launches = nl;
+    if (info) info->launches = nl;
     return SMX_OK;
 }
 

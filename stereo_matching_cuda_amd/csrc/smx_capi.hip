@@ -44,6 +44,8 @@ static thread_local StageTimer g_timer;
 // (smx_agg_v5.hip; an error where it does not apply)
 static thread_local int g_agg_path = SMX_DEFAULT_AGG_PATH;
 static thread_local int g_last_path = 0;
+static thread_local int g_max_chunk = 0;     // smx_set_max_slices_per_launch
+static thread_local AggInfo g_last_info;     // smx_last_agg_chunk
 
 // smx_agg_v4.hip (host orchestration of both fused walkers)
 bool v4_supported(const smx_params* p);
@@ -52,7 +54,8 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                  const uint8_t* const* d_other, const float* const* d_cost, int w, int h,
                  const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
                  uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
-                 hipStream_t st, int* launches, bool fast, int walker, int* walker_used);
+                 hipStream_t st, const AggOpts& opt, AggInfo* info);
+size_t v5_fix_bytes(int w, int h, int nviews);
 int v4_read_status(const void* d_ws, unsigned* out);
 void v4_geometry(int* ow, int* bh);
 // smx_agg_v5.hip
@@ -65,14 +68,17 @@ static int aggregate_fused(int path, const smx_params* p, int nviews, const uint
                            const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
                            uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
                            hipStream_t st, int* launches) {
-    int used = 0;
-    const bool cost_in = d_cost && d_cost[0];
-    if (path == 5 && (cost_in || !v5_supported(p)))
-        return fail(SMX_E_ARG, "aggregation path 5 (comb walker) needs radius 9, costs built from the images and default-like cost parameters");
+    AggOpts opt;
+    opt.fast = path == 4;
+    opt.walker = path == 3 ? 4 : path == 5 ? 5 : 0;
+    opt.max_chunk = g_max_chunk;
+    AggInfo info;
     int rc = aggregate_v4(p, nviews, d_guide, d_other, d_cost, w, h, dmin, s_begin, s_end, d_keys, d_mean_u8,
-                          d_agg, d_ws, ws_bytes, st, launches, path == 4, path == 3 ? 4 : 0, &used);
+                          d_agg, d_ws, ws_bytes, st, opt, &info);
     if (rc) return rc;
-    g_last_path = path == 4 ? 4 : (used == 5 ? 5 : 2);
+    g_last_info = info;
+    if (launches) *launches = info.launches;
+    g_last_path = path == 4 ? 4 : (info.walker_used == 5 ? 5 : 2);
     return SMX_OK;
 }
 
@@ -212,6 +218,25 @@ int smx_set_agg_path(int path) {
 }
 
 int smx_last_agg_path(void) { return g_last_path; }
+
+int smx_set_max_slices_per_launch(int n) {
+    if (n < 0) return fail(SMX_E_ARG, "smx_set_max_slices_per_launch: n must be >= 0 (0 = as many as the workspace holds)");
+    g_max_chunk = n;
+    return SMX_OK;
+}
+
+int smx_last_agg_chunk(int* slices_per_launch, int* walker_launches) {
+    if (slices_per_launch) *slices_per_launch = g_last_info.chunk;
+    if (walker_launches) *walker_launches = g_last_info.walker_launches;
+    return SMX_OK;
+}
+
+// (dev / test hook, not in smx.h: the size of the region the comb walker addresses through one 32-bit-offset descriptor)
+__attribute__((visibility("default"))) int smx_debug_v5_fix_bytes(int w, int h, int nviews, uint64_t* bytes) {
+    SMX_ARG(bytes && w >= 2 && h >= 1 && (nviews == 1 || nviews == 2));
+    *bytes = (uint64_t)v5_fix_bytes(w, h, nviews);
+    return SMX_OK;
+}
 
 int smx_agg_geometry(int radius, int* strip_cols, int* band_rows, int* tile_cols) {
     int ow = 0, bh = 0;

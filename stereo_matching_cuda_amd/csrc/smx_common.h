@@ -4,6 +4,9 @@
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+
+#include <mutex>
 
 #include "smx.h"
 
@@ -48,10 +51,44 @@ inline CostConst make_cost_const(const smx_params* p) {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// A kernel's dynamic-LDS limit, raised ONCE per device to the most its launcher ever asks for (hipFuncSetAttribute is a
+// per-device setting and a runtime call: it does not belong in front of every launch).  One static instance per kernel.
+struct LdsLimitOnce {
+    std::once_flag done[64];
+    hipError_t err[64];
+    hipError_t ensure(const void* fn, int bytes) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const int i = dev & 63;
+        std::call_once(done[i], [&] { err[i] = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+        return err[i];
+    }
+};
+// developer overrides from the environment, read once per process (never per call)
+inline int env_int_once(const char* name, int absent) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : absent;
+}
+
 // Stage boundary of the calling thread's timed call (smx_set_timing(1) / smx_stage_times): records a HIP event of the
 // CURRENT device on `st`; a no-op when timing is off.  Stage ids: smx_capi.hip.
 enum StageId { ST_BEGIN = 0, ST_UPLOAD, ST_GUIDANCE, ST_WALK, ST_WTA, ST_FINISH, ST_DOWNLOAD, ST_COUNT };
 void stage_mark(int stage, hipStream_t st);
+
+// Options / report of one fused aggregation call (smx_agg_v4.hip aggregate_v4; set and read through the C-ABI:
+// smx_set_agg_path, smx_set_max_slices_per_launch, smx_last_agg_path, smx_last_agg_chunk)
+struct AggOpts {
+    bool fast = false;       // FAST mode (not bit-exact)
+    int walker = 0;          // 0 choose, 4 ring walker forced, 5 comb walker forced (an error where it does not apply)
+    int max_chunk = 0;       // upper bound on the slices of one walker launch; 0 = as many as the workspace holds
+};
+struct AggInfo {
+    int walker_used = 0;     // 4 ring walker, 5 comb walker
+    int chunk = 0;           // slices per walker launch (of the first = largest launch)
+    int walker_launches = 0;
+    int launches = 0;        // all kernel launches + memsets of the call
+};
 
 // ---- packed WTA key ---------------------------------------------------------------------
 // key = sord(cost) << 32 | (0xFFFFFFFF - slice), compared as SIGNED 64-bit integers: sord = monotone

@@ -676,8 +676,8 @@ int launch_filter(const smx_params* p, const uint8_t* I, uint8_t* mean, float* v
 int launch_fill_occlusion(const float* src, float* disp, int w, int h, float vMin, hipStream_t st) {
     size_t lds = (size_t)w * 2 * sizeof(float);
     if (lds > 128 * 1024) return fail(SMX_E_ARG, "fill_occlusion: width %d exceeds LDS row buffer", w);
-    if (lds > 64 * 1024)
-        SMX_HIP(hipFuncSetAttribute((const void*)k_fill_occlusion, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static LdsLimitOnce lim;
+    if (lds > 64 * 1024) SMX_HIP(lim.ensure((const void*)k_fill_occlusion, 128 * 1024));
     hipLaunchKernelGGL(k_fill_occlusion, dim3(h), dim3(64), lds, st, src, disp, w, h, vMin);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
@@ -696,8 +696,8 @@ bool finish_pair_row_supported(int w) { return w <= FP_MAXW; }
 int launch_finish_pair_row(const smx_params* p, const int64_t* keys, int w, int h, int dminl, int dminr, int dOcc,
                            float vMin, float* best, float* dmap, float* occlusion, float* filled, hipStream_t st) {
     const size_t lds = (size_t)w * 3 * sizeof(float);
-    if (lds > 64 * 1024)
-        SMX_HIP(hipFuncSetAttribute((const void*)k_finish_pair_row, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static LdsLimitOnce lim;
+    if (lds > 64 * 1024) SMX_HIP(lim.ensure((const void*)k_finish_pair_row, (int)((size_t)FP_MAXW * 3 * sizeof(float))));
     hipLaunchKernelGGL(k_finish_pair_row, dim3(h), dim3(FP_NT), lds, st, keys, w, h, dminl, dminr, dOcc, p->d_lr, vMin,
                        best, dmap, occlusion, filled);
     SMX_HIP(hipGetLastError());

@@ -74,9 +74,13 @@ class PairPipeline:
         """Both views per kernel launch (smx_dev_aggregate_wta_pair)."""
         with self._on_device():
             L, P, st = self.lib, C.byref(self.params), self._stream()
-            _lib.check(L.smx_dev_aggregate_wta_pair(
-                P, _dp(gray_l), _dp(gray_r), self.w, self.h, self.dminl, self.dminr, self.s_begin,
-                self.s_end, _dp(self.keys), _dp(self.mean), _dp(self.agg), _dp(self.ws), self.ws_bytes, st))
+            _lib.check(L.smx_set_max_slices_per_launch(self.slices_in_flight))
+            try:
+                _lib.check(L.smx_dev_aggregate_wta_pair(
+                    P, _dp(gray_l), _dp(gray_r), self.w, self.h, self.dminl, self.dminr, self.s_begin,
+                    self.s_end, _dp(self.keys), _dp(self.mean), _dp(self.agg), _dp(self.ws), self.ws_bytes, st))
+            finally:
+                L.smx_set_max_slices_per_launch(0)
 
     def init_keys(self):
         with self._on_device():
@@ -87,9 +91,20 @@ class PairPipeline:
         agg = self.agg[view] if self.agg is not None else None
         with self._on_device():
             L, P, st = self.lib, C.byref(self.params), self._stream()
-            _lib.check(L.smx_dev_aggregate_wta(
-                P, _dp(guide), _dp(other), _dp(cost), self.w, self.h, dmin, self.s_begin, self.s_end,
-                _dp(self.keys[view]), _dp(self.mean[view]), _dp(agg), _dp(self.ws), self.ws_bytes, st))
+            _lib.check(L.smx_set_max_slices_per_launch(self.slices_in_flight))
+            try:
+                _lib.check(L.smx_dev_aggregate_wta(
+                    P, _dp(guide), _dp(other), _dp(cost), self.w, self.h, dmin, self.s_begin, self.s_end,
+                    _dp(self.keys[view]), _dp(self.mean[view]), _dp(agg), _dp(self.ws), self.ws_bytes, st))
+            finally:
+                L.smx_set_max_slices_per_launch(0)
+
+    def last_chunk(self):
+        """(slices per walker launch, walker launches) of this thread's last fused aggregation: what
+        `slices_in_flight` came to (guidedFilter.cu:171-238 is a loop over single slices)."""
+        c, n = C.c_int(0), C.c_int(0)
+        _lib.check(self.lib.smx_last_agg_chunk(C.byref(c), C.byref(n)))
+        return c.value, n.value
 
     def finish(self):
         """Keys -> best/dmap (reference presets, dispSelect rule), LR check, filling: main.cu:112-155 in one

@@ -154,3 +154,33 @@ def test_integration_md_c_snippets_compile_against_the_headers(tmp_path):
         r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
                             str(src)], capture_output=True, text=True)
         assert r.returncode == 0, f"snippet {k}:\n{b}\n{r.stderr}"
+
+
+def test_comb_walker_descriptor_bound(lib):
+    """The comb walker addresses both image planes, the guidance planes and their comb-ordered copies through ONE buffer
+    descriptor with 32-bit offsets (0x80000000 = "outside the image"): aggregate_v4 picks it only while that region stays
+    below 2 GiB.  The bound is the exact sum of the carved parts, not a per-pixel estimate (round-4 advisor finding: a
+    24 B/pixel guard let 8192x5460 through at ~49 B/pixel).  Pure arithmetic: no GPU."""
+    fn = C.CDLL(_lib.SO_PATH).smx_debug_v5_fix_bytes
+    fn.restype, fn.argtypes = C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+
+    def fix(w, h, nv):
+        b = C.c_uint64()
+        assert fn(w, h, nv, C.byref(b)) == 0
+        return b.value
+    # BASELINE shapes: far inside
+    assert fix(1242, 375, 2) < 64 << 20 and fix(3840, 2160, 2) < 1 << 30
+    # 44.7 Mpix pair: outside (the old guard, h * (w + 8) * 24 < 2^31, passed it)
+    assert 5460 * (8192 + 8) * 24 < 1 << 31 <= fix(8192, 5460, 2)
+    # per-pixel size of the region for a pair: two 4-byte image planes, two 8-byte guidance planes and the comb-ordered
+    # copies (100 B per comb lane slot and band: ~25 B per pixel) -> well above 24 B
+    assert 45 < fix(8192, 5460, 2) / (8192 * 5460) < 60
+    # monotone in both dimensions around the limit, and a single view needs less
+    assert fix(8192, 5000, 2) < fix(8192, 5460, 2) < fix(8400, 5460, 2) and fix(8192, 5460, 1) < fix(8192, 5460, 2)
+
+
+def test_max_slices_per_launch_knob(lib):
+    assert lib.smx_set_max_slices_per_launch(-1) == -1
+    assert lib.smx_set_max_slices_per_launch(7) == 0 and lib.smx_set_max_slices_per_launch(0) == 0
+    c, n = C.c_int(-1), C.c_int(-1)
+    assert lib.smx_last_agg_chunk(C.byref(c), C.byref(n)) == 0 and (c.value, n.value) == (0, 0)   # no aggregation yet on this thread

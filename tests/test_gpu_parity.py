@@ -578,6 +578,11 @@ def test_device_pipeline_chunked_equals_unchunked(tsukuba_gray, tsukuba_oracle, 
     r = _device_pair(Il, Ir, 16, path=path, dminl=-15, dminr=0, slices_in_flight=3)
     for k in KEYS:
         _eq(r[k], tsukuba_oracle[k], k)
+    if path == 2:
+        import ctypes as C
+        c, n = C.c_int(), C.c_int()
+        smx.check(smx.lib().smx_last_agg_chunk(C.byref(c), C.byref(n)))
+        assert (c.value, n.value) == (3, 6), "16 slices, three per launch: six walker launches"
 
 
 def test_workspace_too_small_is_an_error(tsukuba_gray):
@@ -635,6 +640,7 @@ def test_pair_motorcycle_shape_properties():
     dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
     full = PairPipeline(w, h, D, slices_in_flight=70)
     full.run(dl, dr)
+    assert full.last_chunk() == (70, 4), "280 slices, 70 per launch: the running WTA crosses four walker launches"
     ref = full.results()
     keys_full = full.keys.clone()
     assert ref["dmapl"].min() >= -(D - 1) and ref["dmapl"].max() <= 0
@@ -648,6 +654,7 @@ def test_pair_motorcycle_shape_properties():
         s0, s1 = shard_range(D, g, 2)
         pipe = PairPipeline(w, h, D, s_begin=s0, s_end=s1, slices_in_flight=35)
         pipe.aggregate(dl, dr)
+        assert pipe.last_chunk() == (35, 4)
         k = pipe.keys.clone()
         merged = k if merged is None else torch.minimum(merged, k)
     pipe.keys.copy_(merged)
@@ -695,6 +702,7 @@ def test_pair_4k_shape_properties():
     dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
     full = PairPipeline(w, h, D, slices_in_flight=128)
     full.run(dl, dr)
+    assert full.last_chunk() == (128, 4), "512 slices, 128 per launch"
     ref = full.results()
     keys_full = full.keys.clone()
     assert ref["dmapl"].min() >= -(D - 1) and ref["dmapl"].max() <= 0
@@ -709,6 +717,7 @@ def test_pair_4k_shape_properties():
         pipe = PairPipeline(w, h, D, s_begin=s0, s_end=s1, slices_in_flight=24)   # 64 slices, 3 chunks
         pipe.aggregate(dl, dr)
         pipe.check_status()
+        assert pipe.last_chunk() == (24, 3), "a 64-slice shard in launches of 24 + 24 + 16"
         k = pipe.keys.clone()
         merged = k if merged is None else torch.minimum(merged, k)
         if g < 7:
@@ -728,11 +737,12 @@ def test_pair_4k_shape_properties():
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("shape,ranges,sif", [
     ("motorcycle", [(0, 3), (137, 140), (100, 103), (277, 280)], 2),
-    ("4k", [(0, 2), (255, 258), (510, 512)], 2),
+    ("4k", [(0, 3), (255, 258), (509, 512)], 2),
 ])
 def test_full_geometry_slices_equal_the_oracle(orc, shape, ranges, sif):
     """BASELINE configs 3 and 5 pinned to the ORACLE at full geometry (2964x2000 D=280, 3840x2160 D=512) on sampled
-    slice ranges -- first, last, inside, and (slices_in_flight = 2) one that straddles a workspace chunk: aggregated
+    slice ranges -- first, last, inside -- each of three or more slices run with at most two slices per walker launch, so that
+    every range straddles a launch boundary (asserted through smx_last_agg_chunk): aggregated
     planes and the packed keys of the range, bit for bit, through both q layouts of the comb walker (the caller's
     [z][y][x] volume / the comb-ordered scratch + its WTA pass).  The reference overflows its 32-bit sizes at these
     shapes (guidedFilter.cu:6-7,26, costVolume.cu:6,178); a 32-bit offset, band / strip count or chunking defect
@@ -750,6 +760,10 @@ def test_full_geometry_slices_equal_the_oracle(orc, shape, ranges, sif):
             pipe = PairPipeline(w, h, D, s_begin=s0, s_end=s1, slices_in_flight=sif, want_agg=want_agg)
             pipe.aggregate(dl, dr)
             pipe.check_status()
+            # the bound on the slices per launch is what chunks (smx_set_max_slices_per_launch), whatever the workspace holds:
+            # every range here crosses a launch boundary (re-zeroed tickets and flags, reused q scratch and records, the WTA
+            # minimum accumulated over launches, slice * q_plane offsets of the second launch)
+            assert pipe.last_chunk() == (sif, -(-(s1 - s0) // sif)) and pipe.last_chunk()[1] >= 2
             keys = pipe.keys.cpu().numpy()
             _eq(keys[0], keysl, f"{shape} [{s0},{s1}) agg={want_agg} keys l")
             _eq(keys[1], keysr, f"{shape} [{s0},{s1}) agg={want_agg} keys r")

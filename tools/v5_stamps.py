@@ -34,7 +34,8 @@ for it in range(nit):
         print(f"it {it:2d}: iteration {int(nxt.max() - r[:, 0].min()):6d} cycles")
         for wv in range(NW):
             a = r[wv]
-            print(f"   w{wv}: W {a[1]-a[0]:5d} (+wait {a[2]-a[1]:5d})  R {a[3]-a[2]:5d} (+{a[4]-a[3]:5d})  X {a[5]-a[4]:5d} (+{int(nxt[wv]-a[5]):5d})")
+            fine = ("  pairs end at " + " ".join(f"{a[6 + j] - a[4]:5d}" for j in range(5)) + f"  stamp11 {a[11] - a[4]:5d}") if wv < 6 and a[6] > 0 else ""
+            print(f"   w{wv}: W {a[1]-a[0]:5d} (+wait {a[2]-a[1]:5d})  R {a[3]-a[2]:5d} (+{a[4]-a[3]:5d})  X {a[5]-a[4]:5d} (+{int(nxt[wv]-a[5]):5d}){fine}")
 if nit > 8:
     acc = np.zeros((3,))
     accw = np.zeros((3, NW))

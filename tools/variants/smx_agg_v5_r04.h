@@ -6,10 +6,14 @@
 namespace smx {
 namespace v5 {
 
-// Comb length 9: seven combs per wave, three comb waves per stage + a row-scan wave + a cost wave (512 threads, two
-// workgroups per CU at 128 VGPRs); the row scans run beside the comb rows.  (Round 4 also built comb lengths 12 and 16 as
-// three-barrier forms -- slower; tools/variants/ keeps that file.)
-constexpr int L = 9;                    // lanes of a comb
+// Comb length: 16 = one comb per 16-lane DPP row, five comb waves per stage, 640-thread workgroups (only one of
+// which fits a CU: 3 + 3 + 2 + 2 waves per SIMD at 96 VGPRs); 12 = five combs per wave, four comb waves per stage,
+// 512-thread workgroups (two waves per SIMD each: two per CU at 128 VGPRs); 9 = seven combs per wave, three comb
+// waves per stage + a row-scan wave + a cost wave (512 threads): the row scans run beside the comb rows (PIPE)
+#ifndef SMX_V5_L
+#define SMX_V5_L 9
+#endif
+constexpr int L = SMX_V5_L;             // lanes of a comb
 constexpr int CPW = 64 / L;             // combs per wave
 constexpr int NS1 = (19 + CPW - 1) / CPW;   // comb waves per stage
 constexpr int OWS = 19 * (L - 1);       // output columns per strip (19 combs x (L - 1) outputs)
@@ -17,6 +21,7 @@ constexpr int BH = 10;                  // band height
 constexpr int REC_U = 105;              // 16-byte units per hand-off record
 constexpr int WG_PER_CU = 2;
 constexpr int CLP = 64 * NS1;           // comb lane slots per stage and strip
+constexpr bool PIPE = L == 9;           // dedicated scan and cost waves, one workgroup barrier per band
 
 struct Args {
     // the fixed part of the workspace: both image planes [h][w + 2 PADX] of k_v4_prep and the guidance planes

@@ -15,7 +15,7 @@
 //     place by one wave (lane = (stage, row, component), four columns per LDS instruction, the reference's left -> right
 //     order) and read once by the comb lanes.
 //
-// Comb length L = 9 (smx_agg_v5.h), the PIPELINED form: 512 threads = 3 comb waves of stage 1 (p, I p -> a_k,
+// Default build, SMX_V5_L = 9 (smx_agg_v5.h), the PIPELINED form: 512 threads = 3 comb waves of stage 1 (p, I p -> a_k,
 // b_k), 3 comb waves of stage 2 (a, b -> q), one ROW-SCAN wave and one COST wave; seven combs of nine lanes per comb
 // wave, 152 output columns per strip, 128 VGPRs, 79 KB of LDS: two workgroups per CU.  One workgroup barrier (ordering
 // LDS only) per band; in slot sl of an item
@@ -26,8 +26,8 @@
 //   stage-2 combs  the a/b band sl-2 out of tile 2[sl%2] into registers (first thing: the stage-1 waves wait for that
 //                  through an LDS counter before their first store), hand-off record of pass sl-1 -> global (sc1);
 //                  S2 += R2, box, division, q rows [10 sl - 38, 10 sl - 28) -> HBM
-// (The earlier three-barrier forms with comb lengths 12 / 16 -- W / R / X phases, the row scans on wave 0 -- are history:
-// tools/variants/smx_agg_v5_r04_L9_L12_L16.hip, not built into the library.)
+// SMX_V5_L = 12 / 16 build the earlier three-barrier forms (W / R / X phases, the row scans on wave 0): kept as A/B
+// variants (tools/exp_build.sh), not shipped.
 // Hand-off, tickets and the bounded flag waits are those of smx_agg_v4.hip (strip-major tickets: the left neighbour of
 // an item always holds an earlier ticket); every wave takes the flag value it acts on from an LDS word written in the
 // slot before (s_peek), so that all eight waves agree on whether the slot has the extra barrier of a wait.
@@ -55,16 +55,15 @@ namespace v5 {
 using namespace aggdev;
 
 constexpr int R = 9, HW = 2 * R + 1;
-constexpr int SWU = HW * L;             // integral-image columns per strip (171)
+constexpr int SWU = HW * L;             // integral-image columns per strip (304 / 228 / 171)
 constexpr int SW = (SWU + 3) / 4 * 4;   // tile columns: whole quads (the columns behind SWU are never used)
 static_assert(OWS == HW * (L - 1) && SWU == OWS + HW && CPW * L <= 64 && CPW * NS1 >= HW, "strip geometry");
 constexpr int RD = 20;                  // ring slots (>= 2R+2; a multiple of BH: static slots)
 static_assert(RD % BH == 0 && RD >= HW + 1, "ring");
-static_assert(L == 9, "the shipped form: seven combs of nine lanes per comb wave");
-constexpr int NX = 2;                               // a row-scan wave and a cost wave beside the comb waves
-constexpr int NWAVE = 2 * NS1 + NX, NT = 64 * NWAVE;   // 512 threads
-constexpr int WPE = 4;                              // waves per SIMD the register budget is set for (128 VGPRs)
-constexpr int NT1 = 3, NT2 = 2;                     // tile buffers per stage
+constexpr int NX = PIPE ? 2 : 0;                    // PIPE: a row-scan wave and a cost wave beside the comb waves
+constexpr int NWAVE = 2 * NS1 + NX, NT = 64 * NWAVE;   // 640 / 512 / 512 threads
+constexpr int WPE = NWAVE == 8 ? 4 : 5;             // waves per SIMD the register budget is set for (128 / 96 VGPRs)
+constexpr int NT1 = PIPE ? 3 : 2, NT2 = PIPE ? 2 : 1;  // tile buffers per stage
 enum Role { ROLE_S1 = 0, ROLE_S2 = 1, ROLE_SCAN = 2, ROLE_COST = 3 };
 // A tile row is component-planar: first components (p / a) at [0, 304), second ones (I p / b) at [P1, P1 + 304):
 // the row scan moves four columns of one component per LDS instruction, a comb lane reads its cell's pair with
@@ -98,9 +97,7 @@ __device__ unsigned long long g_stamps[10 * STAMP_SLOTS];
 // Diagnostic build only (-DSMX_V5_WHATIF=<bits>): leaves parts of the work out (WRONG results) to see what the
 // kernel time is sensitive to.  1: no row scans; 2: no cost evaluation; 4: no stage-1 comb rows; 8: no stage-2 comb
 // rows; 16: no q stores; 32: no guidance loads; 64: no hand-off (every strip like strip 0); 128: no input loads;
-// 256: row scans without their LDS writes; 512: row scans without the adds; 1024: row scans at normal priority;
-// 2048: no record / flag stores (every strip like the last); 4096: no hand-in (every strip like the first); 8192: the stage-1
-// waves do not wait for the stage-2 copy-out
+// 256: row scans without their LDS writes; 512: row scans without the adds; 1024: row scans at normal priority
 #ifndef SMX_V5_WHATIF
 #define SMX_V5_WHATIF 0
 #endif
@@ -131,10 +128,6 @@ constexpr int WMAP = SMX_V5_WMAP;
 #ifndef SMX_V5_PRIO_SCAN
 #define SMX_V5_PRIO_SCAN 3
 #endif
-#ifndef SMX_V5_S2_KEEP
-#define SMX_V5_S2_KEEP 12
-#endif
-constexpr int S2_KEEP = SMX_V5_S2_KEEP;     // vector-memory operations a stage-2 wave issues behind its record store in an interior slot
 constexpr int PRIO_COST = SMX_V5_PRIO_COST, PRIO_S1 = SMX_V5_PRIO_S1, PRIO_S2HEAD = SMX_V5_PRIO_S2HEAD, PRIO_SCAN = SMX_V5_PRIO_SCAN;
 
 #ifdef SMX_V5_DUMP
@@ -143,24 +136,48 @@ constexpr int PRIO_COST = SMX_V5_PRIO_COST, PRIO_S1 = SMX_V5_PRIO_S1, PRIO_S2HEA
 __device__ float g_dump[2 * TILE_F + NT * 48];
 #endif
 
-// ---- DPP left taps fused into the arithmetic: lane i reads lane i-1 (`wave_shr:1`: the combs of nine lanes are not whole DPP
-// rows, so there is no zero fill in front of a comb).  (The compiler keeps a separate v_mov_b32_dpp per tap; the fused forms
+// ---- DPP left taps fused into the arithmetic: lane i reads lane i-1 (`row_shr:1` with zero fill inside a 16-lane DPP row
+// for combs of 16, `wave_shr:1` otherwise).  (The compiler keeps a separate v_mov_b32_dpp per tap; the fused forms
 // halve the box.)  A VGPR written by the VALU instruction in front may not be read by DPP for two wait states and the
 // compiler's hazard recogniser does not look into inline assembly: box_bottom, whose sources are the column sums of
 // this very row, brings its own s_nop 1; box_top reads ring slots written 19 rows ago.
+#define V5_DPP_SHR "%s row_mask:0xf bank_mask:0xf bound_ctrl:1"
 __device__ __forceinline__ f2 box_bottom(f2 s) {            // s - s[lane-1], both components
     f2 d;
-    asm("s_nop 1\n\tv_subrev_f32_dpp %0, %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    if (L == 16)
+        asm("s_nop 1\n\tv_subrev_f32_dpp %0, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_subrev_f32_dpp %1, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(d.x), "=&v"(d.y) : "v"(s.x), "v"(s.y));
+    else
+        asm("s_nop 1\n\tv_subrev_f32_dpp %0, %2, %2 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
             "v_subrev_f32_dpp %1, %3, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(d.x), "=&v"(d.y) : "v"(s.x), "v"(s.y));
     return d;
 }
 __device__ __forceinline__ f2 box_top(f2 u, f2 t) {         // u + t[lane-1], both components
     f2 d;
-    asm("v_add_f32_dpp %0, %2, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    if (L == 16)
+        asm("v_add_f32_dpp %0, %2, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+            "v_add_f32_dpp %1, %3, %5 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(d.x), "=&v"(d.y) : "v"(t.x), "v"(t.y), "v"(u.x), "v"(u.y));
+    else
+        asm("v_add_f32_dpp %0, %2, %4 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
             "v_add_f32_dpp %1, %3, %5 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=&v"(d.x), "=&v"(d.y) : "v"(t.x), "v"(t.y), "v"(u.x), "v"(u.y));
     return d;
 }
+#undef V5_DPP_SHR
 
+// cost_pair of smx_agg_dev.h with the two truncations as v_min_f32 |d|, <scalar threshold>: the thresholds stay in
+// SGPRs (the generic form canonicalises them into VGPRs that then live through the whole kernel)
+__device__ __forceinline__ f2 cost_pair_s(fg_t q1, fg_t q2, const CostConst& cc) {
+    const f2 v1 = {(float)q1.x, (float)q1.y}, v2 = {(float)q2.x, (float)q2.y};
+    const f2 d = v1 - v2;
+    f2 m;
+    asm("v_min_f32 %0, |%1|, %2" : "=v"(m.x) : "v"(d.x), "s"(cc.th_color));
+    asm("v_min_f32 %0, |%1|, %2" : "=v"(m.y) : "v"(d.y), "s"(cc.th_grad));
+    const f2 xz = (f2){cc.oma, cc.alpha} * m;
+    f2 r;
+    r.x = xz.x + xz.y;
+    r.y = v1.x * r.x;
+    return r;
+}
 // x / area for both components of a cell with ca = (RN(1/area), area) in ONE register pair: div_small_int2 with the
 // operands broadcast by op_sel (low half = 1/area, high half = area) instead of two ready-made pairs
 __device__ __forceinline__ f2 div_ca(f2 x, f2 ca) {
@@ -221,18 +238,18 @@ template <int FASTK>
 __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     __shared__ __attribute__((aligned(16))) float tile1[NT1][TILE_F];
     __shared__ __attribute__((aligned(16))) float tile2s[NT2][TILE_F];
-    __shared__ float cin1s[2][BH][2];                               // stage-1 row carries of the band the next scan pass takes (by pass parity)
+    __shared__ float cin1s[2][BH][2];                               // stage-1 row carries of the band the next scan pass takes (PIPE: by pass parity)
     __shared__ float rcp_s[RCP_N];                                  // RN(1/area)
     __shared__ int s_item, s_next;
     __shared__ unsigned s_seen;                                     // last value read from the left neighbour's flag
-    __shared__ unsigned s_peek[2];                                  // the flag as peeked at during slot sl -> [(sl + 1) & 1], read by every wave at the top of slot sl + 1
+    __shared__ unsigned s_peek[2];                                  // PIPE: the flag as peeked at during slot sl -> [(sl + 1) & 1], read by every wave at the top of slot sl + 1
     __shared__ unsigned s_x1;                                       // stage-2 waves that have taken their rows out of tile 2 (counts up through an item)
 
     const int lane = threadIdx.x & 63;
     const int hwave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // role of a hardware wave (waves w and w + 4 of a workgroup share a SIMD)
-    const int wave = WMAP == 1 ? (int)((0x75436210u >> (4 * hwave)) & 7u) : WMAP == 2 ? (int)((0x54317620u >> (4 * hwave)) & 7u)
-                     : WMAP == 3 ? (int)((0x53764210u >> (4 * hwave)) & 7u) : WMAP == 4 ? (int)((0x57436210u >> (4 * hwave)) & 7u) : hwave;
+    const int wave = PIPE && WMAP == 1 ? (int)((0x75436210u >> (4 * hwave)) & 7u) : PIPE && WMAP == 2 ? (int)((0x54317620u >> (4 * hwave)) & 7u)
+                     : PIPE && WMAP == 3 ? (int)((0x53764210u >> (4 * hwave)) & 7u) : PIPE && WMAP == 4 ? (int)((0x57436210u >> (4 * hwave)) & 7u) : hwave;
     const int tid = 64 * wave + lane;
     const int w = A.w, h = A.h, K = A.K, NI = A.NI, nsv = A.nsv;
     const CostConst cc = A.cc;
@@ -244,9 +261,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     // (per-lane values that only one phase of an iteration needs are re-derived from the thread index where they
     // are used -- a handful of integer instructions per band -- instead of living in VGPRs through the comb rows)
     // comb of this lane = residue rho (>= 19: the lane idles), position il in the comb
-    auto comb_il = [&]() { return opaque(lane) % L; };
+    auto comb_il = [&]() { return L == 16 ? (opaque(lane) & 15) : opaque(lane) % L; };
     auto comb_rho = [&]() {
-        const int l = opaque(lane), c = l / L;
+        const int l = opaque(lane), c = L == 16 ? l >> 4 : l / L;
         return c < CPW ? CPW * (wave - (st2w ? NS1 : 0)) + c : HW;
     };
     auto comb_jt = [&]() {
@@ -256,7 +273,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     // stage-1 inputs (cost evaluation): done by the stage-1 waves that do not scan (waves 1 .. NS1-1), in the shadow of
     // the row scans; NRQ rounds of one quad (four tile columns of one row) per thread, the last round almost full
     constexpr int NQROW = SW / 4;                                   // quads per tile row (76 / 57)
-    constexpr int NCT = 64;                                         // cost threads: the cost wave
+    constexpr int NCT = PIPE ? 64 : 64 * (NS1 - 1);                 // cost threads (PIPE: the cost wave)
     constexpr int NRB = 4;                                          // rounds whose loads are in flight together
     constexpr int NCT2 = 0;
     constexpr int NQT = BH * NQROW;                                 // quads per band
@@ -273,7 +290,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         const int slice = sv - view * A.nslices;
         const int base1 = OWS * k - 1;          // image column of tile-1 column 0
         const int base2 = OWS * k - R - 1;      // image column of tile-2 column 0 (= a/b column of the same comb lane)
-        const bool pred = k > 0 && !(WHATIF & (64 | 4096)), succ = k + 1 < K && !(WHATIF & (64 | 2048));
+        const bool pred = k > 0 && !(WHATIF & 64), succ = k + 1 < K && !(WHATIF & 64);
         const int d = A.d0[view] + slice;
         unsigned* const myflag = A.flags + (size_t)sv * K + k;
         // Buffer descriptors: ONE over the fixed part of the workspace (both image planes, the guidance plane: the
@@ -300,7 +317,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         constexpr int ROLE = decltype(ROLEc)::value;
         constexpr bool ST2 = ROLE == ROLE_S2, COMB = ROLE <= ROLE_S2;
         // the tile-2 buffer the comb rows of stage 1 write / the next scan pass takes for stage 2 and the hand-in fills,
-        // and the stage-1 carries of that pass (they alternate from band to band)
+        // and the stage-1 carries of that pass (PIPE: they alternate from band to band)
         float* tile2 = tile2s[0];
         float (*cin1)[2] = cin1s[0];
         // ---- per-lane constants of the item that every comb row needs ------------------------------------------
@@ -342,12 +359,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // register carries state of the other role around the band loop)
         // guidance of the band's output rows: loaded at the end of R (a barrier and the X1 phase ahead of the rows that
         // use it), consumed row by row in X2
-        // stage 1: (mean_I, 1/(var+eps)) of two a/b rows per entry -- a ring of TWO row pairs: the pair P = 5 sl + j of the band grid
-        // lives in gr[P & 1] = gr[(sl + j) & 1] and is loaded while pair P - 2 is computed, i.e. 2 x ~450 cycles ahead of its use
-        // (round 4 loaded the five pairs of a band in a burst at the end of the slot before -- 20 registers through the rows,
-        // and the burst was waited for in front of the slot barrier)
-        f4 gr[ROLE == ROLE_S1 ? 2 : 1];
-        for (int e = 0; e < (ROLE == ROLE_S1 ? 2 : 1); ++e) gr[e] = (f4){0, 0, 0, 0};
+        f2 gq[ROLE == ROLE_S1 ? BH : 1];     // stage 1: (mean_I, 1/(var+eps)) of the a/b rows
         unsigned gI[ST2 ? BH / 2 : 1];       // stage 2: guidance image values of two q rows each (fp16 pairs)
         f2 r2[ST2 ? BH : 1];                 // stage 2: the band's (R2 a, R2 b) rows, taken out of tile 2 in X(i), used in R(i+1)
 #pragma unroll
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // tile (row, column) of this thread's quad of round r; re-derived from the thread index where it is used (a few
         // integer instructions) instead of living in registers through the comb rows
         auto cost_unit = [&](int r, int& row, int& col, bool& on) {
-            const int u = NCT2 + r * NCT + opaque(lane);
+            const int u = NCT2 + r * NCT + (PIPE ? opaque(lane) : opaque(tid) - 64);
             on = u < NQT;
             const int uc = min(u, NQT - 1);
             row = uc / NQROW;
@@ -373,9 +385,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // Pipelined form: the cost wave evaluates the whole band, NRQ quads per lane.  Per quad, fixed for the item: byte
         // offsets of its four cells in the two image planes (row term included; the band term is the scalar offset of the
         // load), byte offset in a tile, the row term alone and which of the four columns lie in the image (edge items).
-        constexpr int CWN = ROLE == ROLE_COST ? NRQ : 1;
+        constexpr int CWN = (PIPE && ROLE == ROLE_COST) ? NRQ : 1;
         unsigned cw_a1[CWN], cw_a2[CWN], cw_t[CWN], cw_rowb[CWN], cw_m[CWN];
-        if constexpr (ROLE == ROLE_COST) {
+        if constexpr (PIPE && ROLE == ROLE_COST) {
 #pragma unroll
             for (int r = 0; r < NRQ; ++r) {
                 int row, col; bool on;
@@ -453,26 +465,70 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             // (two versions of the whole band: the interior one has no trace of the edge handling)
             if (xedge || BH * ib + BH > h) run(std::true_type{}); else { V5_MARK("cost begin"); run(std::false_type{}); V5_MARK("cost end"); }
         };
+        auto eval_band = [&](int ib, float* dst) {
+            auto off = [&](int row, int col, int dd) {
+                const int y = min(BH * ib + row, h - 1);
+                return (unsigned)(min(max(base1 + col + dd, -PADX), w) + PADX) * 4u + (unsigned)y * fgw4;
+            };
+            const bool edge = xedge || BH * ib + BH > h;
+            auto cell = [&](unsigned a, unsigned b, int row, int c) {
+                f2 v = cost_pair_s(__builtin_bit_cast(fg_t, a), __builtin_bit_cast(fg_t, b), cc);
+                if (edge) {
+                    const int ci = base1 + c;
+                    if (!(ci >= 0 && ci < w && BH * ib + row < h)) v = NZ2;
+                }
+                return v;
+            };
+#pragma unroll
+            for (int r0 = 0; r0 < NRQ; r0 += NRB) {
+                constexpr int NB = NRB;
+                u4 ra[NB], rb[NB];
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    if (r0 + q < NRQ) {
+                        int row, col; bool on;
+                        cost_unit(r0 + q, row, col, on);
+                        ra[q] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(row, col, 0), o_fg1, 0));
+                        rb[q] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)off(row, col, d), o_fg2, 0));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NB; ++q) {
+                    if (r0 + q < NRQ) {
+                        int row, col; bool on;
+                        cost_unit(r0 + q, row, col, on);
+                        const unsigned r1[4] = {ra[q].x, ra[q].y, ra[q].z, ra[q].w}, r2q[4] = {rb[q].x, rb[q].y, rb[q].z, rb[q].w};
+                        float* p = dst + row * RS + col;
+                        if (r0 + q + 1 < NRQ || on) {
+#pragma unroll
+                            for (int jj = 0; jj < 4; jj += 2) {
+                                const f2 v0 = cell(r1[jj], r2q[jj], row, col + jj), v1 = cell(r1[jj + 1], r2q[jj + 1], row, col + jj + 1);
+                                *(f2*)(p + jj) = (f2){v0.x, v1.x};
+                                *(f2*)(p + P1 + jj) = (f2){v0.y, v1.y};
+                            }
+                        }
+                    }
+                }
+            }
+        };
         // guidance of the output rows of iteration ib: FEW, WIDE loads -- a vector-memory instruction costs its wave and the CU's
         // address path the same whatever its width, and ten 8-byte loads per stage-1 wave and band were 700-1000 cycles of its
         // slot.  Stage 1: five 16-byte loads of two rows each (the planes hold row pairs on the band grid: pair P = rows
         // 2 P - 9, 2 P - 8).  Stage 2: the five fp16 row pairs of the band as one 16-byte and one 4-byte load.
-        static_assert(BH == 10, "five row pairs per band");
-        // stage 1: row pair P of the band grid -> its ring entry.  Unconditional (a load under a condition is waited for where the
-        // branches merge); the lane's offset in a row of the plane is re-derived from the lane index -- two instructions -- instead
-        // of living in a register through the rows.  (bit_cast of the whole vector: taking .y/.z/.w of the builtin's result
-        // through a u4 copy let the compiler narrow the load to ONE dword -- wrong results, found by bisection)
-        auto g1_load = [&](int P, auto Sc) {
-            if constexpr (ROLE == ROLE_S1 && !(WHATIF & 32)) {
-                const int Pc = __builtin_amdgcn_readfirstlane(min(max(P, 0), 5 * NI - 1));
-                const unsigned vgl = (unsigned)(64 * wave + opaque(lane)) * 16u;
-                gr[decltype(Sc)::value] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)vgl, o_g1p + Pc * (CLP * 16), 0));
-            }
-        };
         auto issue_guid = [&](int ib, int yq0) {
             if (WHATIF & 32) return;
             const int ibc = __builtin_amdgcn_readfirstlane(min(max(ib, 0), NI - 1));
-            if constexpr (ST2) {
+            if constexpr (ROLE == ROLE_S1) {
+                static_assert(BH == 10, "five row pairs per band");
+#pragma unroll
+                for (int j = 0; j < BH / 2; ++j) {
+                    // (bit_cast of the whole vector: taking .y/.z/.w of the builtin's result through a u4 copy let the compiler narrow the
+                    // load to ONE dword here -- wrong results, found by bisection)
+                    const f4 g = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)vg, o_g1p + (5 * ibc + j) * (CLP * 16), 0));
+                    gq[2 * j] = (f2){g.x, g.y};
+                    gq[2 * j + 1] = (f2){g.z, g.w};
+                }
+            } else if constexpr (ST2) {
                 // (yq0 = 10 (ib - 1) - 18 at every call site: the band grid of the planes)
                 const u4 a = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)(vg * 4u), o_i2p + ibc * (CLP * 16), 0));
                 gI[0] = a.x; gI[1] = a.y; gI[2] = a.z; gI[3] = a.w;
@@ -519,7 +575,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             f4* const r4 = (f4*)row;
             constexpr int NG = SW / 4;
 #ifndef SMX_V5_SCAN_PF
-#define SMX_V5_SCAN_PF 4        // (round 5 A/B on KITTI shape: 4 -> 0.816 ms per pair, 8 -> 0.823, 12 -> 0.819)
+#define SMX_V5_SCAN_PF 8
 #endif
             constexpr int PF = SMX_V5_SCAN_PF;          // groups of reads in flight ahead of the dependent adds
             f4 v[PF];
@@ -552,53 +608,110 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         };
 
         // ---- comb rows ---------------------------------------------------------------------------------------------
-        // (box sum S11 - S10 - S01 + S00, computeBoxFilterOnGPU guidedFilter.cu:305-318, in that order: box_bottom of the ring
-        // slot of the row, minus the slot 19 rows up, box_top with that slot -- the left taps are lane i-1 of the comb)
-        // window area of output row y for this lane in a band whose windows are clipped in y: xw x (window rows inside the image);
-        // RN(1 / area) comes from the table in LDS -- looked up a row PAIR ahead of its use (rcp_pair), so that the LDS latency
-        // is not on the path of the division
-        // (rows outside the image get SOME valid table index -- their outputs are dropped; few scalar instructions matter here: a
-        // border pair that re-derived both its own and the next pair's areas ran 300 cycles longer than an interior one)
-        auto area_ix = [&](int y) {
-            const unsigned yh = min((unsigned)(min(y + R, h - 1) - max(y - R - 1, -1)), (unsigned)HW);
-            return (int)__umul24((unsigned)xw, max(yh, 1u));
+        // box sum S11 - S10 - S01 + S00 (computeBoxFilterOnGPU guidedFilter.cu:305-318, that order) of ring slot SL
+        // (bottom taps) and SL01 (top taps, 19 rows up): left taps = lane i-1 of the DPP row
+#define V5_BOX(u, SL, SL01)                                    \
+    do {                                                       \
+        u = box_bottom(ring[SL]);                              \
+        u = u - ring[SL01];                                    \
+        u = box_top(u, ring[SL01]);                            \
+    } while (0)
+        // (1/area, area) of output row y for this lane (border bands: clipped window height, table look-up)
+        auto area_of = [&](int y, auto BORDERc) {
+            if constexpr (decltype(BORDERc)::value) {
+                const int yc = min(max(y, 0), h - 1);
+                const int yh = min(h - 1, yc + R) - max(-1, yc - R - 1);
+                const int ai = xw * yh;
+                return (f2){rcp_s[ai], (float)ai};
+            } else {
+                return ca_i;
+            }
         };
-        auto rcp_pair = [&](int y) {
-            const int a0 = area_ix(y), a1 = area_ix(y + 1);
-            return (f4){rcp_s[a0], (float)a0, rcp_s[a1], (float)a1};
-        };
-        f4 rcb = {1.0f, 1.0f, 1.0f, 1.0f};   // border bands: (1/area, area) of rows a and b of the NEXT row pair
 
-        // stage-1 role: tile 2 of a band's parity is free once every stage-2 wave has taken the a/b band two bands back out
+        // One comb row of stage 1: T = row of the band, N = T + 10 * (band parity) = ring slot of its image row.
+        // rv = this row's (R1 p, R1 Ip) pair, read from the tile one row ahead; rows are separate scheduling regions
+        // (the compiler otherwise runs the ten column sums first and keeps every tap of the band alive).
+        auto row1 = [&](auto Nc, auto MODEc, int i, const float* t1, f2& rv) {
+            constexpr int N = decltype(Nc)::value, T = N % BH, SL = N, SL01 = (N + 1) % RD, SLP = (N + RD - 1) % RD;
+            constexpr int MODE = decltype(MODEc)::value;     // 0: interior band of an interior strip (straight-line code);
+            constexpr bool BORDER = MODE == 2;               // 1: interior band, strip 0 or one with columns outside the image; 2: border band
+            const std::integral_constant<bool, BORDER> BORDERc;
+            const f2 rvn = tile_rd(t1 + (T + 1 < BH ? T + 1 : T) * RS + jt);
+            ring[SL] = rv + ring[SLP];                     // colSum integral.cu:124-128
+            f2 u;
+            V5_BOX(u, SL, SL01);
+            if (L != 16 && MODE != 0) {
+                // combs that are not whole DPP rows get no zero fill: the first lane of a comb of strip 0 (its a/b
+                // columns 0 .. 8 are outputs) takes the box without left taps instead
+                const f2 u0 = ring[SL] - ring[SL01];
+                if (il0 && k == 0) u = u0;
+            }
+            const f2 ca1 = area_of(BH * i - R + T, BORDERc);
+            const f2 m = FASTK ? div_ca_q(u, ca1) : div_ca(u, ca1);   // (mean_p, mean_Ip); no window sum of p, I p can be tiny (smx_agg_v5.h)
+            const f2 g = gq[T];
+            // compute_ak_and_bk guidedFilter.cu:345-354
+            const float mm = g.x * m.x;
+            const float ak = 1.0f * (m.y - mm) * g.y;
+            const float mb2 = 1.0f * g.x * ak;
+            const float bk = 1.0f * m.x - mb2;
+            // a/b row 10 i - 9 + T -> tile 2 (scanned in R(i+1)); rows / columns outside the image: -0
+            f2 ab = {ak, bk};
+            if (MODE != 0) {
+                const int ya = BH * i - R + T;
+                if (!(col_ok && ya >= 0 && ya < h)) ab = NZ2;
+            }
+            tile_wr(tile2 + T * RS + jw, ab);
+            rv = rvn;
+            if (T & 1) __builtin_amdgcn_sched_barrier(0);    // (regions of two rows: the second fills the wait states of the first)
+        };
+        // one comb row of stage 2, run in R(i) on the a/b band i-2 (same parity as i): ring slot of a/b row 10 (i-2) - 9 + T
+        auto row2 = [&](auto Nc, auto BORDERc, int i) {
+            constexpr int N = decltype(Nc)::value, T = N % BH, PAR = N / BH;
+            constexpr int SL = (BH * PAR + T + 11) % RD, SL01 = (SL + 1) % RD, SLP = (SL + RD - 1) % RD;
+            constexpr bool BORDER = decltype(BORDERc)::value;
+            ring[SL] = r2[T] + ring[SLP];
+            f2 u;
+            V5_BOX(u, SL, SL01);
+            const int yq = BH * (i - 2) - 2 * R + T;
+            const f2 ca = area_of(yq, BORDERc);
+            f2 m = FASTK ? div_ca_q(u, ca) : div_ca(u, ca);
+            // tiny (or zero) window sums of a, b take the true division (wave-uniform, rare); lanes without an
+            // output do not vote
+            float amin = 1.0f;
+            if (!FASTK) asm("v_min_f32 %0, |%1|, |%2|" : "=v"(amin) : "v"(u.x), "v"(u.y));
+            if (!FASTK && (__builtin_amdgcn_ballot_w64(!(amin >= 0x1p-100f)) & okmask) != 0) {
+                asm volatile("; exact-division slow path");
+                m.x = 1.0f * u.x / ca.y;
+                m.y = 1.0f * u.y / ca.y;
+            }
+            const fg_t ip = __builtin_bit_cast(fg_t, gI[T / 2]);
+            const float Iv = (float)(T & 1 ? ip.y : ip.x);
+            const float tq = m.x * Iv;                     // compute_q guidedFilter.cu:363-369
+            const float qv = tq + m.y;
+            if (!(WHATIF & 16) && (!BORDER || (yq >= 0 && yq < h)))
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qv), r_q, (int)vo, q_row0 + yq * q_pitch, AUX_NT);
+            if (T & 1) __builtin_amdgcn_sched_barrier(0);
+        };
+
+        // Two comb rows of stage 1 at once, interior band of an interior strip (MODE 0 of row1): the two dependent chains
+        // interleaved by hand, so that neither the wait states behind a packed operation nor the s_nop in front of a DPP
+        // read stay empty.  N0 = ring slot of the first row (even).
+        // PIPE, stage-1 role: tile 2 of a band's parity is free once every stage-2 wave has taken the a/b band two bands back out
         // of it (they do that first thing in the slot and count up s_x1); waited for right in front of the first a/b store
         unsigned x1_need = 0;
         auto wait_x1 = [&]() {
-            if (WHATIF & 8192) return;
             for (unsigned spins = 0; __hip_atomic_load(&s_x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < x1_need; ++spins) {
                 __builtin_amdgcn_s_sleep(1);
                 if (spins > (1u << 24)) { flag_store(A.status, 1u + (unsigned)item); break; }   // (cannot happen: every wave reaches its increment)
             }
             asm volatile("" ::: "memory");
         };
-        // BORDER: a band with windows clipped in y (the first and last two of an image): per-row window areas from the table,
-        // a/b rows outside the image become -0; it carries the x-edge handling along (EDGE), so that there are three
-        // instantiations, not four.  (Round 4 ran border bands row by row, `row1`: 1 500-2 000 cycles more per slot, ten of an
-        // item's 43 slots -- 8 % of the kernel.)
-        auto rows1_pair = [&](auto N0c, auto EDGEc, auto BORDERc, auto WAITc, int i, const float* t1, f2& rv) {
-            f2 caa = ca_i, cab = ca_i;
-            f4 rcn = {1.0f, 1.0f, 1.0f, 1.0f};
-            constexpr int N0 = decltype(N0c)::value, T0 = N0 % BH, GS = (N0 / BH + T0 / 2) & 1;
-            constexpr bool BORDER = decltype(BORDERc)::value;
-            constexpr bool EDGE = decltype(EDGEc)::value || BORDER;   // strip 0 or one with columns outside the image
+        auto rows1_pair = [&](auto N0c, auto EDGEc, auto WAITc, int i, const float* t1, f2& rv) {
+            constexpr int N0 = decltype(N0c)::value, T0 = N0 % BH;
+            constexpr bool EDGE = decltype(EDGEc)::value;   // strip 0 or one with columns outside the image (interior band)
             constexpr int SLa = N0, SLb = N0 + 1, SLPa = (N0 + RD - 1) % RD, S01a = (N0 + 1) % RD, S01b = (N0 + 2) % RD;
             const f2 rvb = tile_rd(t1 + (T0 + 1) * RS + jt);
             const f2 rvn = tile_rd(t1 + (T0 + 2 < BH ? T0 + 2 : T0 + 1) * RS + jt);
-            const int ya = BH * i - R + T0;            // a/b rows ya, ya + 1
-            if constexpr (decltype(BORDERc)::value) {
-                caa = (f2){rcb.x, rcb.y};
-                cab = (f2){rcb.z, rcb.w};
-                rcn = rcp_pair(ya + 2);
-            }
             const f2 old_a = ring[S01a];               // (slot S01a == SLb: the top taps of row a are what row b overwrites)
             ring[SLa] = rv + ring[SLPa];               // colSum integral.cu:124-128
             f2 ua = box_bottom(ring[SLa]);
@@ -608,24 +721,24 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             ua = box_top(ua, old_a);
             ring[SLb] = sb;
             ub = ub - ring[S01b];
-            if constexpr (EDGE) {
+            if constexpr (EDGE && L != 16) {
                 // (no zero fill in front of a comb that is not a whole DPP row: the first lane of a comb of strip 0 -- its a/b
                 // columns 0 .. 8 are outputs -- takes the box without left taps)
                 const f2 u0a = ring[SLa] - old_a;
                 if (il0 && k == 0) ua = u0a;
             }
-            const f2 qa = div_ca_q(ua, caa);
+            const f2 qa = div_ca_q(ua, ca_i);
             ub = box_top(ub, ring[S01b]);
-            if constexpr (EDGE) {
+            if constexpr (EDGE && L != 16) {
                 const f2 u0b = sb - ring[S01b];
                 if (il0 && k == 0) ub = u0b;
             }
-            const f2 qb = div_ca_q(ub, cab);
+            const f2 qb = div_ca_q(ub, ca_i);
             f2 ma = qa, mb = qb;                       // (mean_p, mean_Ip)
-            if constexpr (!FASTK) ma = div_ca_m(div_ca_e(qa, ua, caa), qa, caa);
-            const f2 ga = {gr[GS].x, gr[GS].y}, gb = {gr[GS].z, gr[GS].w};
+            if constexpr (!FASTK) ma = div_ca_m(div_ca_e(qa, ua, ca_i), qa, ca_i);
+            const f2 ga = gq[T0], gb = gq[T0 + 1];
             const float mma = ga.x * ma.x;             // compute_ak_and_bk guidedFilter.cu:345-354
-            if constexpr (!FASTK) mb = div_ca_m(div_ca_e(qb, ub, cab), qb, cab);
+            if constexpr (!FASTK) mb = div_ca_m(div_ca_e(qb, ub, ca_i), qb, ca_i);
             const float ta = ma.y - mma;
             const float mmb = gb.x * mb.x;
             const float aka = 1.0f * ta * ga.y;
@@ -636,36 +749,18 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             const float mb2b = 1.0f * gb.x * akb;
             f2 aba = {aka, bka};
             if (EDGE && !col_ok) aba = NZ2;            // a/b columns outside the image: -0
-            if (BORDER && !(ya >= 0 && ya < h)) aba = NZ2;          // ... and rows
             if constexpr (decltype(WAITc)::value) wait_x1();
             tile_wr(tile2 + T0 * RS + jw, aba);
             const float bkb = 1.0f * mb.x - mb2b;
             f2 abb = {akb, bkb};
             if (EDGE && !col_ok) abb = NZ2;
-            if (BORDER && !(ya + 1 >= 0 && ya + 1 < h)) abb = NZ2;
             tile_wr(tile2 + (T0 + 1) * RS + jw, abb);
             rv = rvn;
-            // the pair that takes this ring entry next (the band's last pair leaves that to the end of the slot, behind the
-            // hand-in, whose wait for the record -- the compiler makes it a wait for every load in flight -- then finds only
-            // the load of the pair before, issued ~500 cycles earlier)
-            if constexpr (T0 != BH - 2) g1_load(5 * i + T0 / 2 + 2, std::integral_constant<int, GS>{});
-            if constexpr (BORDER) rcb = rcn;
             __builtin_amdgcn_sched_barrier(0);
         };
-        // the same for stage 2; one vote on tiny window sums for both rows.  BORDER: per-row window areas, only the q rows
-        // inside the image are stored (and vote)
-        auto rows2_pair = [&](auto N0c, auto BORDERc, int i) {
+        // the same for stage 2 (interior band); one vote on tiny window sums for both rows
+        auto rows2_pair = [&](auto N0c, int i) {
             constexpr int N0 = decltype(N0c)::value, T0 = N0 % BH, PAR = N0 / BH;
-            constexpr bool BORDER = decltype(BORDERc)::value;
-            const int yq = BH * (i - 2) - 2 * R + T0;
-            const bool va = !BORDER || (yq >= 0 && yq < h), vb = !BORDER || (yq + 1 >= 0 && yq + 1 < h);
-            f2 caa = ca_i, cab = ca_i;
-            f4 rcn = {1.0f, 1.0f, 1.0f, 1.0f};
-            if constexpr (BORDER) {
-                caa = (f2){rcb.x, rcb.y};
-                cab = (f2){rcb.z, rcb.w};
-                rcn = rcp_pair(yq + 2);
-            }
             constexpr int SLa = (BH * PAR + T0 + 11) % RD, SLb = (SLa + 1) % RD, SLPa = (SLa + RD - 1) % RD, S01a = SLb, S01b = (SLb + 1) % RD;
             const f2 old_a = ring[S01a];
             ring[SLa] = r2[T0] + ring[SLPa];
@@ -676,51 +771,38 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             ua = box_top(ua, old_a);
             ring[SLb] = sb;
             ub = ub - ring[S01b];
-            const f2 qa = div_ca_q(ua, caa);
+            const f2 qa = div_ca_q(ua, ca_i);
             ub = box_top(ub, ring[S01b]);
-            const f2 qb = div_ca_q(ub, cab);
+            const f2 qb = div_ca_q(ub, ca_i);
             f2 ma = qa, mb = qb;
-            // tiny (or zero, or non-finite) window sums of a, b take the true division (wave-uniform, rare); lanes without an
-            // output do not vote
-            bool tiny = false;
+            float amin = 1.0f;
             if constexpr (!FASTK) {
-                ma = div_ca_m(div_ca_e(qa, ua, caa), qa, caa);
-                if constexpr (!BORDER) {
-                    float amin;
-                    asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(amin) : "v"(ua.x), "v"(ua.y), "v"(ub.x));
-                    mb = div_ca_m(div_ca_e(qb, ub, cab), qb, cab);
-                    asm("v_min_f32 %0, %1, |%2|" : "=v"(amin) : "v"(amin), "v"(ub.y));
-                    tiny = !(amin >= 0x1p-100f);
-                } else {
-                    // (a row outside the image has no output and does not vote: its window sums are zero)
-                    float m1, m2;
-                    asm("v_min_f32 %0, |%1|, |%2|" : "=v"(m1) : "v"(ua.x), "v"(ua.y));
-                    mb = div_ca_m(div_ca_e(qb, ub, cab), qb, cab);
-                    asm("v_min_f32 %0, |%1|, |%2|" : "=v"(m2) : "v"(ub.x), "v"(ub.y));
-                    tiny = (va && !(m1 >= 0x1p-100f)) || (vb && !(m2 >= 0x1p-100f));
-                }
+                ma = div_ca_m(div_ca_e(qa, ua, ca_i), qa, ca_i);
+                asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(amin) : "v"(ua.x), "v"(ua.y), "v"(ub.x));
+                mb = div_ca_m(div_ca_e(qb, ub, ca_i), qb, ca_i);
+                asm("v_min_f32 %0, %1, |%2|" : "=v"(amin) : "v"(amin), "v"(ub.y));
             }
-            if (!FASTK && (__builtin_amdgcn_ballot_w64(tiny) & okmask) != 0) {
+            if (!FASTK && (__builtin_amdgcn_ballot_w64(!(amin >= 0x1p-100f)) & okmask) != 0) {
                 asm volatile("; exact-division slow path");
-                ma.x = 1.0f * ua.x / caa.y; ma.y = 1.0f * ua.y / caa.y;
-                mb.x = 1.0f * ub.x / cab.y; mb.y = 1.0f * ub.y / cab.y;
+                ma.x = 1.0f * ua.x / ca_i.y; ma.y = 1.0f * ua.y / ca_i.y;
+                mb.x = 1.0f * ub.x / ca_i.y; mb.y = 1.0f * ub.y / ca_i.y;
             }
             const fg_t ip = __builtin_bit_cast(fg_t, gI[T0 / 2]);
+            const int yq = BH * (i - 2) - 2 * R + T0;
             const float tqa = ma.x * (float)ip.x;      // compute_q guidedFilter.cu:363-369
             const float tqb = mb.x * (float)ip.y;
             const float qva = tqa + ma.y;
             const float qvb = tqb + mb.y;
             if (!(WHATIF & 16)) {
-                if (va) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qva), r_q, (int)vo, q_row0 + yq * q_pitch, AUX_NT);
-                if (vb) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qvb), r_q, (int)vo, q_row0 + (yq + 1) * q_pitch, AUX_NT);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qva), r_q, (int)vo, q_row0 + yq * q_pitch, AUX_NT);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qvb), r_q, (int)vo, q_row0 + (yq + 1) * q_pitch, AUX_NT);
             }
-            if constexpr (BORDER) rcb = rcn;
             __builtin_amdgcn_sched_barrier(0);
         };
 
         // hand-in of record `rec` (stage-1 role, strips with a left neighbour): stage-2 halo columns -> tile 2 (scanned
         // around in R(rec)), stage-1 row carries -> LDS
-        auto hand_in = [&](bool halo, const f4 hreg) {
+        auto hand_in = [&](bool halo) {
             const int hq = hu_idx();
             if (hq >= 0 && hq < NHU) {
                 if (halo) {
@@ -737,7 +819,162 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             }
         };
 
-        // ===================================== the slot loop: the row scans run beside the comb rows =======================
+        if constexpr (!PIPE) {
+        // ===================================== the band loop ==============================================
+        // prologue: stage-1 inputs of band 0 -> tile 1[0]; guidance of the first rows; the left neighbour's record 0
+        if (pred) {
+            if (tid == 0) spin_pred(1u);
+            wg_barrier();
+            seen = s_seen;
+        }
+        if constexpr (!ST2) fetch_rec(0);
+        have_pref = pred;
+        if constexpr (!ST2) { if (wave != 0) eval_band(0, tile1[0]); }
+
+        if constexpr (!ST2) { if (pred) hand_in(false); }
+
+        auto band = [&](auto PARc, int i) {
+            constexpr int PAR = decltype(PARc)::value;
+            float* const t1 = tile1[PAR];
+            float* const t1n = tile1[PAR ^ 1];
+            wg_barrier();
+#ifdef SMX_V5_DUMP
+            if (item == SMX_V5_DUMP && i == SMX_V5_DUMP_IT && SMX_V5_DUMP_PH == 0) {
+                for (int e = tid; e < TILE_F; e += NT) { g_dump[e] = t1[e]; g_dump[TILE_F + e] = tile2[e]; }
+                wg_barrier();
+            }
+#endif
+            // ------------------------------------ R(i) --------------------------------------------------
+            V5_STAMP(0);
+            if constexpr (!ST2) {
+                if (wave == 0) {
+                    if (!(WHATIF & 1024) && A.prio) __builtin_amdgcn_s_setprio(PRIO_SCAN);
+                    if (!(WHATIF & 1)) rowscans(i, i - 1, t1, tile2, cin1);
+                    __builtin_amdgcn_s_setprio(0);
+                } else if (!(WHATIF & 2)) {
+                    // the stage-1 inputs of band i+1 -> the other tile-1 buffer, in the shadow of the row scans
+                    eval_band(i + 1, t1n);
+                }
+                issue_guid(i, 0);
+            } else {
+                if (wave == NWAVE - 1 && lane == 63) {
+                    // an otherwise idle lane looks at the left neighbour's flag for the prefetch of record i+1
+                    if (pred && seen != FLAG_DONE && seen < (unsigned)i + 2u) s_seen = flag_load(myflag - 1);
+                    // ticket of the next item, one iteration before the end
+                    if (i == NI - 1)
+                        s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // the comb rows of stage 2 on the a/b band i-2 (taken out of tile 2 in X(i-1)): in the shadow of the row scans
+                if (i >= 2) {
+                    const int yq0 = BH * (i - 2) - 2 * R;
+                    const bool border = yq0 < R + 1 || yq0 + BH - 1 > h - 1 - R;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(WHATIF & 8)) {
+#define V5_R2(TT, B) row2(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, i);
+#define V5_P2(TT) rows2_pair(std::integral_constant<int, BH * PAR + TT>{}, i);
+                    if (border) { V5_R2(0, true) V5_R2(1, true) V5_R2(2, true) V5_R2(3, true) V5_R2(4, true) V5_R2(5, true) V5_R2(6, true) V5_R2(7, true) V5_R2(8, true) V5_R2(9, true) }
+                    else { V5_P2(0) V5_P2(2) V5_P2(4) V5_P2(6) V5_P2(8) }
+                    }
+#undef V5_R2
+#undef V5_P2
+                }
+                // every storing wave drains its global accesses before the barrier behind which one lane publishes
+                // the record stored in X(i-1)
+                drain_vmem();
+            }
+            V5_STAMP(1);
+            wg_barrier();
+            V5_STAMP(2);
+#ifdef SMX_V5_DUMP
+            if (item == SMX_V5_DUMP && i == SMX_V5_DUMP_IT && SMX_V5_DUMP_PH == 1) {
+                for (int e = tid; e < TILE_F; e += NT) { g_dump[e] = t1[e]; g_dump[TILE_F + e] = tile2[e]; }
+                wg_barrier();
+            }
+#endif
+            // ------------------------------------ X(i) ---------------------------------------------------
+            if (succ && tid == NT - 1 && i >= 1) flag_store(myflag, (unsigned)i);
+            seen = s_seen;
+            f2 rv = NZ2;
+            if constexpr (ST2) {
+                // stage 2 takes the a/b band i-1 (scanned in R(i)) out of tile 2: its comb rows run in R(i+1)
+#pragma unroll
+                for (int t = 0; t < BH; ++t) r2[t] = tile_rd(tile2 + t * RS + jt);
+                const int hq = hu_idx();
+                if (succ && hq >= 0 && hq < REC_U) {
+                    // record i: stage-2 row prefix of the strip's last 19 columns (a/b band i-1), stage-1 row carries
+                    f4 hov;
+                    if (hq < NHU) {
+                        const int t = hq / 10, j = (hq - 10 * t) * 2;
+                        const float* p = tile2 + t * RS + OWS + j;
+                        hov = (f4){p[0], p[P1], p[1], p[P1 + 1]};
+                    } else {
+                        const float* p = t1 + 2 * (hq - NHU) * RS + OWS - 1;
+                        hov = (f4){p[0], p[P1], p[RS], p[RS + P1]};
+                    }
+                    st16_sc1(r_hand, (unsigned)(o_out + i * REC_U * 16) + (unsigned)hq * 16u, hov);
+                }
+                // this wave has what it needs from tile 2: tell the stage-1 waves, which overwrite it with the a_k, b_k of
+                // this band (a counter instead of a workgroup barrier: they rarely get there before it is complete)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r2[0]), "+v"(r2[1]), "+v"(r2[2]), "+v"(r2[3]), "+v"(r2[4]), "+v"(r2[5]),
+                             "+v"(r2[6]), "+v"(r2[7]), "+v"(r2[8]), "+v"(r2[9]) :: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&s_x1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                V5_STAMP(3);
+                V5_STAMP(4);
+                // guidance image values of the q rows of R(i+1)
+                issue_guid(i, BH * (i - 1) - 2 * R);
+            } else {
+                // the left neighbour's record i+1 is needed at the end of this iteration: its load goes out now
+                // (unconditionally: a load under a condition is waited for where the branches merge); what it
+                // returns counts only if the record had been published
+                fetch_rec(min(i + 1, NI - 1));
+                rv = tile_rd(t1 + jt);
+                V5_STAMP(3);
+                // tile 2 is free once every stage-2 wave has its rows: the a_k, b_k of this band go straight into it
+                const unsigned need = (unsigned)NS1 * (unsigned)(i + 1);
+                for (unsigned spins = 0; __hip_atomic_load(&s_x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need; ++spins) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (spins > (1u << 24)) { flag_store(A.status, 1u + (unsigned)item); break; }   // (cannot happen: every wave reaches its increment)
+                    }
+                V5_STAMP(4);
+                // an interior band: every window of its a/b rows is unclipped in y
+                const bool border = BH * i - R < R + 1 || BH * i - R + BH - 1 > h - 1 - R;
+                __builtin_amdgcn_sched_barrier(0);
+                if (!(WHATIF & 4)) {
+#define V5_R1(TT, M) row1(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<int, M>{}, i, t1, rv);
+#define V5_P1(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::false_type{}, std::false_type{}, i, t1, rv);
+                if (border) { V5_R1(0, 2) V5_R1(1, 2) V5_R1(2, 2) V5_R1(3, 2) V5_R1(4, 2) V5_R1(5, 2) V5_R1(6, 2) V5_R1(7, 2) V5_R1(8, 2) V5_R1(9, 2) }
+                else if (xedge || k == 0) { V5_R1(0, 1) V5_R1(1, 1) V5_R1(2, 1) V5_R1(3, 1) V5_R1(4, 1) V5_R1(5, 1) V5_R1(6, 1) V5_R1(7, 1) V5_R1(8, 1) V5_R1(9, 1) }
+                else { V5_P1(0) V5_P1(2) V5_P1(4) V5_P1(6) V5_P1(8) }
+                }
+#undef V5_R1
+#undef V5_P1
+            }
+            have_pref = pred && (seen == FLAG_DONE || seen >= (unsigned)i + 2u);
+            // ---- hand-in of record i+1 (needed by R(i+1)): prefetched at the top of X1 if it had been published
+            if (pred && !have_pref && i + 1 < NI) {
+                // the neighbour had not published it when this item looked: wait for it now
+                if (tid == 0) spin_pred((unsigned)i + 2u);
+                wg_barrier();
+                seen = s_seen;
+                if constexpr (!ST2) fetch_rec(min(i + 1, NI - 1));
+            }
+            if constexpr (!ST2) { if (pred && i + 1 < NI) hand_in(true); }
+            V5_STAMP(5);
+#ifdef SMX_V5_DUMP
+            if (item == SMX_V5_DUMP && i == SMX_V5_DUMP_IT && SMX_V5_DUMP_PH == 2) {
+                wg_barrier();
+                for (int e = tid; e < TILE_F; e += NT) { g_dump[e] = t1[e]; g_dump[TILE_F + e] = tile2[e]; }
+#pragma unroll
+                for (int s = 0; s < RD; ++s) { g_dump[2 * TILE_F + tid * 48 + 2 * s] = ring[s].x; g_dump[2 * TILE_F + tid * 48 + 2 * s + 1] = ring[s].y; }
+            }
+#endif
+        };
+        for (int i = 0; i < NI; i += 2) {
+            band(std::integral_constant<int, 0>{}, i);
+            if (i + 1 < NI) band(std::integral_constant<int, 1>{}, i + 1);
+        }
+        } else {
+        // ============================= PIPE: the row scans run beside the comb rows ===============================
         // Scan pass s (s = -1 .. NI-2) = stage-1 band s+1 and the a/b band s-1, by the scan wave during slot s; slot s also
         // has the comb rows of stage 1 on band s (scanned in pass s-1) and of stage 2 on the a/b band s-2 (scanned in pass
         // s-1, taken out of its tile at the start of the slot), and the cost wave's band s+2.  ONE workgroup barrier per slot.
@@ -754,9 +991,8 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         have_pref = pred;
         if constexpr (ROLE == ROLE_S1) {
             fetch_rec(0);
-            g1_load(0, std::integral_constant<int, 0>{});
-            g1_load(1, std::integral_constant<int, 1>{});
-            if (pred) { cin1 = CI(-1); hand_in(false, hreg); }
+            issue_guid(0, 0);
+            if (pred) { cin1 = CI(-1); hand_in(false); }
         }
         if constexpr (ROLE == ROLE_COST) eval_band_p(0, T1(0));
         auto slot = [&](auto PARc, int sl) {
@@ -799,23 +1035,24 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     if (A.prio) __builtin_amdgcn_s_setprio(PRIO_S1);
                     x1_need = (unsigned)NS1 * (unsigned)(sl + 1);
                     const bool border = BH * sl - R < R + 1 || BH * sl - R + BH - 1 > h - 1 - R;
-                    if (WHATIF & 4) wait_x1();                  // (the rows wait in front of their first store)
+                    if (border || (WHATIF & 4)) wait_x1();      // (the interior rows wait in front of their first store)
                     V5_STAMP(4);
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(WHATIF & 4)) {
-#define V5_P1(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::false_type{}, std::false_type{}, std::integral_constant<bool, TT == 0>{}, sl, t1, rv);
-#define V5_P1E(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::true_type{}, std::false_type{}, std::integral_constant<bool, TT == 0>{}, sl, t1, rv);
-#define V5_P1B(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::true_type{}, std::true_type{}, std::integral_constant<bool, TT == 0>{}, sl, t1, rv);
-                    if (border) { rcb = rcp_pair(BH * sl - R); V5_P1B(0) V5_STAMP(6); V5_P1B(2) V5_STAMP(7); V5_P1B(4) V5_STAMP(8); V5_P1B(6) V5_STAMP(9); V5_P1B(8) V5_STAMP(10); }
+#define V5_R1(TT, M) row1(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<int, M>{}, sl, t1, rv);
+#define V5_P1(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::false_type{}, std::integral_constant<bool, TT == 0>{}, sl, t1, rv);
+#define V5_P1E(TT) rows1_pair(std::integral_constant<int, BH * PAR + TT>{}, std::true_type{}, std::integral_constant<bool, TT == 0>{}, sl, t1, rv);
+                    if (border) { V5_R1(0, 2) V5_R1(1, 2) V5_R1(2, 2) V5_R1(3, 2) V5_R1(4, 2) V5_R1(5, 2) V5_R1(6, 2) V5_R1(7, 2) V5_R1(8, 2) V5_R1(9, 2) }
                     else if (xedge || k == 0) { V5_P1E(0) V5_P1E(2) V5_P1E(4) V5_P1E(6) V5_P1E(8) }
                     else { V5_MARK("s1rows begin"); V5_P1(0) V5_STAMP(6); V5_P1(2) V5_STAMP(7); V5_P1(4) V5_STAMP(8); V5_P1(6) V5_STAMP(9); V5_P1(8) V5_STAMP(10); V5_MARK("s1rows end"); }
                     }
+#undef V5_R1
 #undef V5_P1
 #undef V5_P1E
-#undef V5_P1B
 #ifndef SMX_V5_PRIO_S1TAIL
                     __builtin_amdgcn_s_setprio(0);
 #endif
+                    issue_guid(sl + 1, 0);
                     V5_STAMP(11);
                 }
             } else {
@@ -851,53 +1088,37 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     __builtin_amdgcn_s_setprio(0);
                     V5_STAMP(3);
                     V5_STAMP(4);
-                    [[maybe_unused]] bool s2_interior = false;
                     if (sl >= 2) {
                         const int yq0 = BH * (sl - 2) - 2 * R;
                         const bool border = yq0 < R + 1 || yq0 + BH - 1 > h - 1 - R;
-                        s2_interior = !border && !(WHATIF & (8 | 16 | 32));
                         __builtin_amdgcn_sched_barrier(0);
                         if (!(WHATIF & 8)) {
-#define V5_P2(TT) rows2_pair(std::integral_constant<int, BH * PAR + TT>{}, std::false_type{}, sl);
-#define V5_P2B(TT) rows2_pair(std::integral_constant<int, BH * PAR + TT>{}, std::true_type{}, sl);
-                        if (border) { rcb = rcp_pair(yq0); V5_P2B(0) V5_STAMP(6); V5_P2B(2) V5_STAMP(7); V5_P2B(4) V5_STAMP(8); V5_P2B(6) V5_STAMP(9); V5_P2B(8) V5_STAMP(10); }
+#define V5_R2(TT, B) row2(std::integral_constant<int, BH * PAR + TT>{}, std::integral_constant<bool, B>{}, sl);
+#define V5_P2(TT) rows2_pair(std::integral_constant<int, BH * PAR + TT>{}, sl);
+                        if (border) { V5_R2(0, true) V5_R2(1, true) V5_R2(2, true) V5_R2(3, true) V5_R2(4, true) V5_R2(5, true) V5_R2(6, true) V5_R2(7, true) V5_R2(8, true) V5_R2(9, true) }
                         else { V5_MARK("s2rows begin"); V5_P2(0) V5_STAMP(6); V5_P2(2) V5_STAMP(7); V5_P2(4) V5_STAMP(8); V5_P2(6) V5_STAMP(9); V5_P2(8) V5_STAMP(10); V5_MARK("s2rows end"); }
                         }
+#undef V5_R2
 #undef V5_P2
-#undef V5_P2B
                     }
                     issue_guid(sl, BH * (sl - 1) - 2 * R);
                     // the record stored above is complete in memory before the barrier behind which it is published
-                    // (vector-memory operations of a wave complete in issue order: what was issued behind the record store -- the
-                    // ten q rows of an interior band and the two guidance loads -- may stay in flight; -DSMX_V5_S2_KEEP=0: the
-                    // full drain of round 4)
-                    if (S2_KEEP > 0 && s2_interior) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(S2_KEEP) : "memory"); else
                     drain_vmem();
                 }
             }
             // ---- hand-in of the record of pass sl+1 (index sl+2), prefetched at the top of the slot if it had been published
             have_pref = pred && (seen == FLAG_DONE || seen >= (unsigned)sl + 3u);
-            // (two copies of the hand-in on purpose: the prefetched record is OLDER than the guidance loads of this slot, so its
-            // wait leaves those in flight; a record fetched again behind the flag wait is the newest load, and one merged copy
-            // would wait for everything -- it did: every stage-1 wave sat out its five guidance loads in front of the slot barrier)
             if (pred && !have_pref && sl + 2 < NI) {
                 if (tid == 0) spin_pred((unsigned)sl + 3u);
                 wg_barrier();
                 seen = s_seen;
-                if constexpr (ROLE == ROLE_S1) {
-                    const int hq = hu_idx();
-                    const f4 late = ld16_sc1(r_hand, (unsigned)(o_in + min(sl + 2, NI - 1) * REC_U * 16) + (hq >= 0 && hq < REC_U ? (unsigned)hq * 16u : 0u));
-                    cin1 = CI(sl + 1); tile2 = T2(sl);
-                    hand_in(sl >= 0, late);
-                }
-            } else if constexpr (ROLE == ROLE_S1) {
-                // (the halo is that of the a/b band sl, which the comb rows above have just written into the same tile)
-                V5_MARK("s1handin begin");
-                if (pred && sl + 2 < NI) { cin1 = CI(sl + 1); tile2 = T2(sl); hand_in(sl >= 0, hreg); }
-                V5_MARK("s1handin end");
+                if constexpr (ROLE == ROLE_S1) fetch_rec(min(sl + 2, NI - 1));
             }
             if constexpr (ROLE == ROLE_S1) {
-                if (sl >= 0) g1_load(5 * sl + 6, std::integral_constant<int, PAR>{});     // (pair 4 of this slot used entry (PAR + 4) & 1)
+                // (the halo is that of the a/b band sl, which the comb rows above have just written into the same tile)
+                V5_MARK("s1handin begin");
+                if (pred && sl + 2 < NI) { cin1 = CI(sl + 1); tile2 = T2(sl); hand_in(sl >= 0); }
+                V5_MARK("s1handin end");
 #ifdef SMX_V5_PRIO_S1TAIL
                 __builtin_amdgcn_s_setprio(0);
 #endif
@@ -909,12 +1130,15 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             slot(std::integral_constant<int, 0>{}, sl);
             if (sl + 1 < NI) slot(std::integral_constant<int, 1>{}, sl + 1);
         }
+        }
         };
         if (tid == 0) { s_x1 = 0u; s_peek[0] = 0u; s_peek[1] = 0u; }   // (ordered before the first use by the barrier at the top of the first band)
         if (wave < NS1) item_body(std::integral_constant<int, ROLE_S1>{});
         else if (wave < 2 * NS1) item_body(std::integral_constant<int, ROLE_S2>{});
-        else if (wave == 2 * NS1) item_body(std::integral_constant<int, ROLE_SCAN>{});
-        else item_body(std::integral_constant<int, ROLE_COST>{});
+        else if constexpr (PIPE) {
+            if (wave == 2 * NS1) item_body(std::integral_constant<int, ROLE_SCAN>{});
+            else item_body(std::integral_constant<int, ROLE_COST>{});
+        }
         // the last record and the last q rows: drained, then published
         drain_vmem();
         wg_barrier();
@@ -924,6 +1148,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         }
     }
 }
+#undef V5_BOX
 
 // ---------------------------------------------------------------------------------------------------------------
 // comb-ordered guidance planes: grid (K * h, nviews), block CLP
@@ -1087,7 +1312,7 @@ bool v5_supported(const smx_params* p) {
     auto ok = [](float t) { return t == 0.0f || t >= 0x1p-60f; };
     if (!(ok(t1) && ok(t2))) return false;
     // the pipelined form truncates in packed halves: thresholds exact (and finite) in fp16
-    if (!((float)(_Float16)c.th_color == c.th_color && (float)(_Float16)c.th_grad == c.th_grad && c.th_color < 60000.0f && c.th_grad < 60000.0f))
+    if (v5::PIPE && !((float)(_Float16)c.th_color == c.th_color && (float)(_Float16)c.th_grad == c.th_grad && c.th_color < 60000.0f && c.th_grad < 60000.0f))
         return false;
     return true;
 }
@@ -1097,8 +1322,10 @@ int v5_launch(const v5::Args& a, hipStream_t st) {
     SMX_HIP(hipGetDevice(&dev));
     SMX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     int per_cu = v5::WG_PER_CU;                          // persistent: WG_PER_CU workgroups per CU
-    static const int env_per_cu = env_int_once("SMX_V5_WG_PER_CU", 0);   // experiments: fewer workgroups per CU
-    if (env_per_cu >= 1 && env_per_cu <= v5::WG_PER_CU) per_cu = env_per_cu;
+    if (const char* e = getenv("SMX_V5_WG_PER_CU")) {    // experiments: fewer workgroups per CU
+        const int v = atoi(e);
+        if (v >= 1 && v <= v5::WG_PER_CU) per_cu = v;
+    }
     const int slots = per_cu * ncu;
     const int grid = a.nitems < slots ? a.nitems : slots;
     if (a.fast) hipLaunchKernelGGL((v5::k_v5_walk<1>), dim3((unsigned)grid), dim3(v5::NT), 0, st, a);
