@@ -47,7 +47,12 @@ def main():
     ap.add_argument("--workload", default="kitti", choices=["tsukuba", "kitti", "motorcycle", "4k"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--preheat-s", type=float, default=0.3, help="seconds of untimed steps in front of the warmup steps")
-    ap.add_argument("--slices-in-flight", type=int, default=None)
+    ap.add_argument("--slices-in-flight", type=int, default=None,
+                    help="upper bound on the slices of one walker launch (default: all local slices in one launch)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 exchange step: nccl = RCCL over xGMI, one GPU per rank (what the "
+                         "scaling run uses); gloo = the SAME control flow with the keys staged through host memory, ranks may "
+                         "share a GPU (rehearsal of the N > 1 path on a one-GPU box; not a performance number)")
     args = ap.parse_args()
 
     import numpy as np
@@ -65,11 +70,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit(f"--backend nccl needs one GPU per rank ({world} ranks, {ndev} devices); --backend gloo lets ranks share a GPU")
+    dev_index = local_rank % ndev          # (gloo rehearsal: ranks may share a device)
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     smx.lib()  # fail loudly if the HIP extension is missing
     if args.mode == "fast":
@@ -144,9 +156,10 @@ def main():
     dt = time.perf_counter() - t0
     pipe.check_status()       # ... and the status word is per call: read it before the next call clears it
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    chunk, walker_launches = pipe.last_chunk()      # what `slices_in_flight` came to in the timed steps
 
     # ---- the same K steps again, instrumented: HIP events around every step and call (torch, current stream) and around
     # every stage inside the C-ABI (smx_set_timing(2): events on the stream the kernels are launched on, no
@@ -176,6 +189,10 @@ def main():
     # the walker kernel alone: its launches between the stage events of the C-ABI, summed over the timed region
     # (chunked workspaces: several launches per call, each over its share of the cells)
     ncalls = max(1, stage.calls) if stage_rc == 0 else 0
+    if stage_rc == 0 and (stage.calls != args.steps or stage.dropped):
+        # (the C-ABI keeps at most 32768 stage marks: a longer instrumented pass would average a truncated set)
+        print(f"bench.py: stage events of {stage.calls} calls for {args.steps} steps, {stage.dropped} marks dropped -- stage "
+              "times cover only the recorded ones", file=sys.stderr)
     walk_avg_s = stage.aggregation / ncalls * 1e-3 if ncalls else 0.0
     achieved = ALGO_BYTES_PER_CELL * cells_per_call / walk_avg_s / 1e9 if walk_avg_s > 0 else operator_achieved
 
@@ -184,8 +201,8 @@ def main():
     # correction calibrated on a kernel with a known byte count).  Only valid for the profiled config.
     traffic = None
     traffic_src = None
-    tname = {"kitti": "r04_traffic.json", "motorcycle": "r04_motorcycle_traffic.json",
-             "4k": "r04_4k_traffic.json"}.get(args.workload) if args.mode == "exact" else None
+    tname = {"kitti": "r05_traffic.json", "motorcycle": "r05_motorcycle_traffic.json",
+             "4k": "r05_4k_traffic.json"}.get(args.workload) if args.mode == "exact" else None
     tpath = os.path.join(ROOT, "profiles", tname) if tname else None
     if world == 1 and tpath and args.slices_in_flight is None and os.path.exists(tpath):
         try:
@@ -220,7 +237,9 @@ def main():
         "config": {"workload": f"{args.workload} {w}x{h} D={D} seeded synthetic pair (seed {seed})",
                    "width": w, "height": h, "disparities": D,
                    "sharding": f"disparity slices / {world} ranks" if world > 1 else "none",
-                   "slices_in_flight": pipe.slices_in_flight, "library": smx.lib().smx_version().decode()},
+                   "backend": args.backend if world > 1 else None,
+                   "slices_in_flight": chunk, "walker_launches_per_call": walker_launches,
+                   "library": smx.lib().smx_version().decode()},
         "instrumented_pass": {
             "what": "the same K steps run a second time with HIP events around every step, call and stage; `step_ms`, "
                     "`roofline.avg_launch_ms`, `stage_ms_per_call` and `operator.call_ms` are from this pass (events cost "
@@ -230,6 +249,7 @@ def main():
         "step_ms": spread(step_ms),
         "roofline": {
             "bound": "hbm",
+            "scope": "walker_kernel",     # frac / achieved / avg_launch_ms: the dominant KERNEL (rounds 1-3 quoted the whole call: `operator`)
             "kernel": "fused guided-filter aggregation walker, both views per launch (k_v5_walk; k_v4_walk where the comb "
                       "walker does not apply)",
             "achieved": achieved,

@@ -171,6 +171,11 @@ int smx_dev_integral(const float* d_in, float* d_out, int w, int h, int nplanes,
  * hand-off records, control words.  The first 256 bytes hold the call's status word
  * (smx_dev_agg_status).  Fewer slices in flight than s_end - s_begin only means more launches. */
 size_t smx_agg_workspace_bytes(int w, int h, int nslices);
+/* The same for the path that `p` will run in auto mode: with radius <= 9 the fused walker needs ONE plane per slice in
+ * flight (plus its hand-off records), about a quarter of the radius-agnostic bound above, which has to cover the five
+ * planes per slice of the multi-kernel path (radius > 9, or smx_set_agg_path(1)).  At 3840x2160 this is what lets all 512
+ * slices of a volume go out in one launch inside 64 GB. */
+size_t smx_agg_workspace_bytes_for(const smx_params* p, int w, int h, int nslices);
 
 /* Guided-filter aggregation + running winner-take-all over slices [s_begin, s_end) of ONE
  * volume (reference: guidedFilter.cu:171-238 incl. dispSelectOnGPU :403-411).
@@ -271,10 +276,12 @@ void smx_unpack_key(int64_t key, float* cost, uint32_t* slice);
  *   guidance statistics (guidedFilter.cu:58-123);  aggregation: the fused walker (or the multi-kernel passes);
  *   wta: the packed-key pass over the aggregated planes;  finish: decode, LR check, filling (main.cu:112-155).
  * smx_set_timing: 0 off, 1 the times of the LAST call, 2 cumulative over every call since it was switched on
- * (`calls` counts them; up to 4096 stage marks, later ones are dropped). */
+ * (`calls` counts them; up to 32768 stage marks, later ones are counted in `dropped`).  The pipelined entry
+ * (smx_ctx_stereo_pair_async) records no stage marks. */
 typedef struct smx_stage_ms {
     float upload, guidance, aggregation, wta, finish, download, total;
     int calls;
+    int dropped;   /* stage marks that did not fit (mode 2 keeps 32768): > 0 means the sums cover only the first calls */
 } smx_stage_ms;
 int smx_set_timing(int mode);
 int smx_stage_times(smx_stage_ms* out);

@@ -35,7 +35,7 @@ class Params(C.Structure):
 
 class StageMs(C.Structure):
     _fields_ = [(k, C.c_float) for k in ("upload", "guidance", "aggregation", "wta", "finish", "download", "total")] + \
-               [("calls", C.c_int)]
+               [("calls", C.c_int), ("dropped", C.c_int)]
 
 
 class PairOut(C.Structure):
@@ -81,6 +81,7 @@ SIGNATURES = {
     "smx_dev_cost_volume": (_i, [_PP, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "smx_dev_integral": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "smx_agg_workspace_bytes": (_sz, [_i, _i, _i]),
+    "smx_agg_workspace_bytes_for": (_sz, [_PP, _i, _i, _i]),
     "smx_dev_aggregate_wta": (_i, [_PP, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "smx_dev_aggregate_wta_pair": (_i, [_PP, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "smx_dev_agg_status": (_i, [_vp]),

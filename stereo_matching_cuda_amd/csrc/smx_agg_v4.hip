@@ -1567,10 +1567,18 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             }
             b.fast = fast ? 1 : 0;
             {
-                // role priorities pay on launches whose volume stays moderate (measured: KITTI +4 %, <= 4 Mpix x 128 slices
-                // +1-2 %; Motorcycle / 4K -3-4 %): switched by the cells of the launch
-                const double cells = (double)a.nsv * (double)w * (double)h;
-                b.prio = cells < 1.5e9 ? 1 : 0;
+                // Role priorities (smx_agg_v5.hip PRIO_*).  Measured in rounds 4 and 5 (tools/prio_ab*.sh, profiles/r05_prio_*):
+                // they are worth 2-7 % on every launch whose aggregated planes stay within a few GB -- KITTI geometry up to
+                // 1 500 slices (5.7 GB of q), Motorcycle / 4K geometry with few slices, every aspect ratio at KITTI's volume --
+                // and cost 0.4-4.8 % on 4K (34 GB of q per launch); Motorcycle (15 GB) came out at -3.8 %, +3.0 % and -1.7 % on
+                // three boxes.  The counters of the losing case (profiles/r05_prio_pmc_motorcycle.txt): identical instruction
+                // counts, vector-memory operations 32 % longer in flight, 30 % more cycles in s_waitcnt.  What in a large q
+                // footprint does that is not established (address translation of 512 workgroups streaming into planes 27-33 MB
+                // apart is the suspect); the rule is therefore stated in the variable the effect follows: the q bytes of the
+                // launch.  SMX_V5_PRIO=0/1 (read once per process) overrides it for A/B runs.
+                constexpr double PRIO_MAX_Q_BYTES = 6e9;
+                const double q_bytes = (double)a.nsv * (double)qplane * 4.0;
+                b.prio = q_bytes < PRIO_MAX_Q_BYTES ? 1 : 0;
                 static const int env_prio = env_int_once("SMX_V5_PRIO", -1);     // (A/B runs)
                 if (env_prio >= 0) b.prio = env_prio != 0;
             }

@@ -982,10 +982,11 @@ struct Wta5Args {
     const float* q[2];
     int64_t* keys[2];
 };
-// EPL = elements per lane: 4 (16-byte loads), 2 (8-byte loads; needs an even strip row OWS... the rows are OWS = 209 floats, so pairs
-// are taken over the whole plane: K h OWS even and 8-byte aligned planes) or 1
-template <int EPL>
+// Four elements per lane, 16-byte loads: a strip row is OWS = 152 floats, so a plane is a whole number of quads, and the
+// planes are carved 256-byte aligned (aggregate_v4)
+static_assert(OWS % 4 == 0, "quads do not straddle strip rows");
 __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K, int count, int slice0) {
+    constexpr int EPL = 4;
     const size_t np = (size_t)K * h * OWS;
     const size_t e0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * EPL;
     if (e0 >= np) return;
@@ -1020,7 +1021,7 @@ __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K
         for (int t = 0; t < U; ++t)
 #pragma unroll
             for (int j = 0; j < EPL; ++j) {
-                const int64_t kk = pack_key(EPL == 1 ? v[t][0] : v[t][j], (uint32_t)(slice0 + z + t));
+                const int64_t kk = pack_key(v[t][j], (uint32_t)(slice0 + z + t));
                 key[j] = kk < key[j] ? kk : key[j];
             }
     }
@@ -1028,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K
         const fv v = __builtin_nontemporal_load((const fv*)&q[(size_t)z * np]);
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {
-            const int64_t kk = pack_key(EPL == 1 ? v[0] : v[j], (uint32_t)(slice0 + z));
+            const int64_t kk = pack_key(v[j], (uint32_t)(slice0 + z));
             key[j] = kk < key[j] ? kk : key[j];
         }
     }
@@ -1056,19 +1057,10 @@ int v5_wta_launch(int nviews, const float* const* q, int64_t* const* keys, int w
     for (int v = 0; v < 2; ++v) { wa.q[v] = q[v < nviews ? v : 0]; wa.keys[v] = keys[v < nviews ? v : 0]; }
     const int K = v5::strips(w);
     const size_t np = (size_t)K * h * v5::OWS;
-    bool al8 = np % 2 == 0;
-    for (int v = 0; v < nviews; ++v) al8 = al8 && ((uintptr_t)wa.q[v] & 7) == 0;
-    bool al16 = np % 4 == 0;        // 16-byte loads (four elements per lane) where the planes allow
-    for (int v = 0; v < nviews; ++v) al16 = al16 && ((uintptr_t)wa.q[v] & 15) == 0;
-    if (al16)
-        hipLaunchKernelGGL(v5::k_v5_wta<4>, dim3((unsigned)((np / 4 + 255) / 256), (unsigned)nviews), dim3(256), 0, st, wa, w, h,
-                           K, count, slice0);
-    else if (al8)
-        hipLaunchKernelGGL(v5::k_v5_wta<2>, dim3((unsigned)((np / 2 + 255) / 256), (unsigned)nviews), dim3(256), 0, st, wa, w, h,
-                           K, count, slice0);
-    else
-        hipLaunchKernelGGL(v5::k_v5_wta<1>, dim3((unsigned)((np + 255) / 256), (unsigned)nviews), dim3(256), 0, st, wa, w, h, K,
-                           count, slice0);
+    for (int v = 0; v < nviews; ++v)
+        if (((uintptr_t)wa.q[v] & 15) != 0) return fail(SMX_E_ARG, "v5_wta_launch: q scratch of view %d is not 16-byte aligned", v);
+    hipLaunchKernelGGL(v5::k_v5_wta, dim3((unsigned)((np / 4 + 255) / 256), (unsigned)nviews), dim3(256), 0, st, wa, w, h, K,
+                       count, slice0);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }

@@ -13,6 +13,8 @@ namespace smx {
 static thread_local std::string g_err;
 static thread_local int g_timing = 0;        // 0 off, 1 the last call, 2 cumulative over calls
 static thread_local int g_launches = 0;
+static thread_local int g_in_ctx = 0;        // inside a persistent-context entry: the entry marks ST_BEGIN itself, nested calls do not
+static thread_local int g_marks_dropped = 0;
 // Stage timing of the calling thread (smx_set_timing / smx_stage_times): a list of (stage, event) marks of the
 // last timed call; the time between two consecutive marks belongs to the stage of the later one.  Events are taken
 // from a pool per device (an event records on the device that was current when it was created).
@@ -84,8 +86,9 @@ static int aggregate_fused(int path, const smx_params* p, int nviews, const uint
 
 void stage_mark(int stage, hipStream_t st) {
     if (!g_timing) return;
-    if (stage == ST_BEGIN && g_timing == 1) g_timer.begin();
-    if (g_timer.marks.size() >= 4096) return;
+    if (stage == ST_BEGIN && g_in_ctx > 1) return;       // (a device-pointer call nested in a context entry: one call, one ST_BEGIN)
+    if (stage == ST_BEGIN && g_timing == 1) { g_timer.begin(); g_marks_dropped = 0; }
+    if (g_timer.marks.size() >= 32768) { ++g_marks_dropped; return; }
     hipEvent_t e = g_timer.get();
     if (!e || hipEventRecord(e, st) != hipSuccess) return;
     g_timer.marks.push_back({stage, e});
@@ -148,6 +151,7 @@ int smx_set_timing(int mode) {
     if (mode < 0 || mode > 2) return fail(SMX_E_ARG, "smx_set_timing: mode must be 0, 1 or 2");
     g_timing = mode;
     g_timer.begin();
+    g_marks_dropped = 0;
     return SMX_OK;
 }
 
@@ -165,6 +169,7 @@ int smx_stage_times(smx_stage_ms* out) {
         acc[g_timer.marks[i].stage] += t;
     }
     out->calls = calls;
+    out->dropped = g_marks_dropped;
     out->upload = acc[ST_UPLOAD]; out->guidance = acc[ST_GUIDANCE]; out->aggregation = acc[ST_WALK];
     out->wta = acc[ST_WTA]; out->finish = acc[ST_FINISH]; out->download = acc[ST_DOWNLOAD];
     out->total = out->upload + out->guidance + out->aggregation + out->wta + out->finish + out->download;
@@ -209,6 +214,14 @@ size_t smx_agg_workspace_bytes(int w, int h, int nslices) {
     const size_t v1 = plane_bytes(w, h) * (5 + 5 * (size_t)nslices) + 2 * WS_ALIGN;
     const size_t f = v4_workspace_bytes(w, h, nslices);
     return v1 > f ? v1 : f;
+}
+
+size_t smx_agg_workspace_bytes_for(const smx_params* p, int w, int h, int nslices) {
+    if (!p || w < 1 || h < 1 || nslices < 1) return 0;
+    // radius <= 9 runs a fused walker (unless the multi-kernel path is forced: smx_set_agg_path(1) callers size with
+    // smx_agg_workspace_bytes): image / guidance planes, per slice ONE q plane + the hand-off records
+    if (v4_supported(p)) return v4_workspace_bytes(w, h, nslices);
+    return smx_agg_workspace_bytes(w, h, nslices);
 }
 
 int smx_set_agg_path(int path) {
@@ -681,6 +694,9 @@ static int ctx_enqueue(smx_ctx* c, const uint8_t* dL, const uint8_t* dR, int dmi
     int rc;
     const int64_t nn = (int64_t)n;
     int64_t* keysL = c->keys.as<int64_t>(); int64_t* keysR = keysL + n;
+    if (c->agg_path >= 2 && !v4_supported(p))
+        return fail(SMX_E_ARG, "smx_ctx_stereo_pair: fused path forced but radius > 9");
+    struct Nest { Nest() { g_in_ctx += 2; } ~Nest() { g_in_ctx -= 2; } } nest;     // (nested smx_dev_* calls do not restart the stage marks)
     // cost volumes are materialised only when the caller asks for them (main.cu:80-82) and then feed
     // the aggregation like in the reference; otherwise the slices are built on the fly inside it.
     if (want_cost) {
@@ -793,6 +809,9 @@ int smx_ctx_stereo_pair_async(smx_ctx* c, const uint8_t* gray_l, const uint8_t* 
     if (c->submitted - c->waited >= 2)
         return fail(SMX_E_ARG, "smx_ctx_stereo_pair_async: two pairs are in flight already (smx_ctx_wait takes the older one)");
     if ((rc = ctx_async_setup(c))) return rc;
+    // no stage marks in the pipelined entry: pairs overlap on three streams, so "the stages of the last call" has no meaning
+    // here, and an event record per stage is a bubble on the queue the pipeline exists to keep full
+    struct Pause { int saved; Pause() : saved(g_timing) { g_timing = 0; } ~Pause() { g_timing = saved; } } pause;
     const size_t n = c->n, fb = n * sizeof(float);
     smx_ctx::Slot& sl = c->slot[c->submitted & 1];
     // the caller's images into the slot's pinned staging: the caller's buffers are free again when this call returns

@@ -6,7 +6,13 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "smx_rccl.h"
@@ -65,12 +71,69 @@ struct Shard {
     }
 };
 
-// a grouped RCCL section that is closed on every path
-struct NcclGroup {
-    bool open = false;
-    ncclResult_t start() { ncclResult_t r = ncclGroupStart(); open = r == ncclSuccess; return r; }
-    ncclResult_t end() { open = false; return ncclGroupEnd(); }
-    ~NcclGroup() { if (open) (void)ncclGroupEnd(); }
+// One host thread per device, alive as long as the context: a pair is ~12 kernel launches, two uploads and one collective
+// per device, and ONE thread feeding eight devices in turn puts ~100 serial runtime calls in front of a 0.3 ms shard
+// (round-4 review).  A worker sets its device once, then runs the jobs the owner hands it; the error text of a failing
+// job (thread-local in both libraries) travels back with its return code.
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<int()> job;
+    bool has_job = false, done = true, quit = false;
+    int rc = SMX_OK;
+    char msg[512] = {0};
+    void start(int dev) {
+        th = std::thread([this, dev] {
+            (void)hipSetDevice(dev);
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                cv.wait(lk, [this] { return has_job || quit; });
+                if (quit) return;
+                has_job = false;
+                lk.unlock();
+                const int r = job();
+                lk.lock();
+                rc = r;
+                snprintf(msg, sizeof(msg), "%s", r == SMX_OK ? "" : g_msg);
+                done = true;
+                cv.notify_all();
+            }
+        });
+    }
+    void post(std::function<int()> f) {
+        std::lock_guard<std::mutex> lk(m);
+        job = std::move(f);
+        has_job = true;
+        done = false;
+        cv.notify_all();
+    }
+    int wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [this] { return done; });
+        return rc;
+    }
+    ~Worker() {
+        if (!th.joinable()) return;
+        { std::lock_guard<std::mutex> lk(m); quit = true; cv.notify_all(); }
+        th.join();
+    }
+};
+
+// all workers of a pair meet here between the aggregation and the exchange: a collective is only started when EVERY
+// rank has come this far without an error (a rank that failed earlier would leave the others' collectives hanging)
+struct Rendezvous {
+    std::mutex m;
+    std::condition_variable cv;
+    int n = 0, arrived = 0, generation = 0;
+    std::atomic<int> failed{0};
+    void arrive(bool ok) {
+        if (!ok) failed.store(1);
+        std::unique_lock<std::mutex> lk(m);
+        const int gen = generation;
+        if (++arrived == n) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != gen; });
+    }
 };
 
 }  // namespace
@@ -80,6 +143,8 @@ struct smx_sharded_ctx {
     int w = 0, h = 0, size_d = 0, ngpu = 0, flags = 0;
     size_t n = 0;
     std::vector<Shard> sh;
+    std::vector<std::unique_ptr<Worker>> workers;     // one per device (declared behind `sh`: joined before the shards go)
+    Rendezvous meet;
     // decode + LR check + filling on device 0
     float *best = nullptr, *map = nullptr, *occ = nullptr, *fil = nullptr;
     ~smx_sharded_ctx() {
@@ -156,6 +221,12 @@ int smx_sharded_create(const smx_params* p, int w, int h, int size_d, int ngpu, 
     RC_HIP(hipMalloc((void**)&c->map, 2 * fb));
     RC_HIP(hipMalloc((void**)&c->occ, fb));
     RC_HIP(hipMalloc((void**)&c->fil, fb));
+    c->meet.n = ngpu;
+    for (int g = 0; g < ngpu; ++g) {
+        c->workers.emplace_back(new (std::nothrow) Worker);
+        if (!c->workers.back()) return fail(SMX_E_HIP, "%s: %s (line %d)", "smx_sharded_create", "out of host memory", __LINE__);
+        c->workers.back()->start(g);
+    }
     guard.c = nullptr;
     *out = c;
     return SMX_OK;
@@ -170,20 +241,17 @@ int smx_sharded_destroy(smx_sharded_ctx* c) {
     return SMX_OK;
 }
 
-int smx_sharded_run(smx_sharded_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r, int dminl, int dminr,
-                    const smx_pair_out* out) {
-    if (!c || !gray_l || !gray_r || !out)
-        return fail(SMX_E_ARG, "%s: %s (line %d)", "smx_sharded_run", "bad argument", __LINE__);
-    if (out->cost_l || out->cost_r || out->agg_l || out->agg_r)
-        return fail(SMX_E_ARG, "%s: %s (line %d)", "smx_sharded_run", "cost / agg outputs are not available in the sharded driver", __LINE__);
+// What device g does for one pair, on its own host thread: upload, aggregation + running WTA of its slice range, the
+// exchange step on the exchange stream, (device 0: decode + LR check + filling + download), synchronise, status.
+static int shard_pair(smx_sharded_ctx* c, int g, const uint8_t* gray_l, const uint8_t* gray_r, int dminl, int dminr,
+                      const smx_pair_out* out) {
     const smx_params* p = &c->p;
-    const int w = c->w, h = c->h, ngpu = c->ngpu;
+    const int w = c->w, h = c->h;
     const size_t n = c->n;
     const bool per_view = (c->flags & SMX_SHARDED_OVERLAP_VIEWS) != 0;
     const bool all_ranks = (c->flags & SMX_SHARDED_ALLREDUCE) != 0;
-    // upload + local aggregation + running WTA of every device's slice range (asynchronous, all devices busy)
-    for (int g = 0; g < ngpu; ++g) {
-        Shard& s = c->sh[g];
+    Shard& s = c->sh[g];
+    auto enqueue = [&]() -> int {
         RC_HIP(hipSetDevice(g));
         RC_HIP(hipMemcpyAsync(s.L, gray_l, n, hipMemcpyHostToDevice, s.st));
         RC_HIP(hipMemcpyAsync(s.R, gray_r, n, hipMemcpyHostToDevice, s.st));
@@ -201,53 +269,61 @@ int smx_sharded_run(smx_sharded_ctx* c, const uint8_t* gray_l, const uint8_t* gr
                                               s.ws_bytes, s.st));
             RC_HIP(hipEventRecord(s.ev_view[1], s.st));
         }
+        return SMX_OK;
+    };
+    const int rc_a = enqueue();
+    c->meet.arrive(rc_a == SMX_OK);
+    if (c->meet.failed.load()) {
+        (void)hipStreamSynchronize(s.st);
+        return rc_a != SMX_OK ? rc_a : fail(SMX_E_HIP, "%s: %s (line %d)", "smx_sharded_run", "another rank failed before the exchange", __LINE__);
     }
-    // the one exchange step, on the exchange streams; grouped because one thread drives all ranks.  Only
-    // device 0 needs the reassembled maps (ncclReduce) unless the caller asked for them on every rank.
+    // the one exchange step, on the exchange stream (every rank calls its collective from its own thread: no group).
+    // Only device 0 needs the reassembled maps (ncclReduce) unless the caller asked for them on every rank.
     const int nex = per_view ? 2 : 1;
     for (int x = 0; x < nex; ++x) {
-        int64_t* off = nullptr;
         const int64_t cnt = per_view ? (int64_t)n : (int64_t)(2 * n);
-        for (int g = 0; g < ngpu; ++g) {
-            RC_HIP(hipSetDevice(g));
-            RC_HIP(hipStreamWaitEvent(c->sh[g].cst, c->sh[g].ev_view[per_view ? x : 1], 0));
-        }
-        NcclGroup grp;
-        RC_NCCL(grp.start());
-        for (int g = 0; g < ngpu; ++g) {
-            Shard& s = c->sh[g];
-            RC_HIP(hipSetDevice(g));
-            off = s.keys + (per_view ? (size_t)x * n : 0);
-            if (all_ranks) RC_SMX(smx_wta_allreduce(off, cnt, s.comm, s.cst));
-            else RC_SMX(smx_wta_reduce(off, cnt, 0, s.comm, s.cst));
-        }
-        RC_NCCL(grp.end());
+        int64_t* off = s.keys + (per_view ? (size_t)x * n : 0);
+        RC_HIP(hipStreamWaitEvent(s.cst, s.ev_view[per_view ? x : 1], 0));
+        if (all_ranks) RC_SMX(smx_wta_allreduce(off, cnt, s.comm, s.cst));
+        else RC_SMX(smx_wta_reduce(off, cnt, 0, s.comm, s.cst));
     }
-    for (int g = 0; g < ngpu; ++g) {
-        RC_HIP(hipSetDevice(g));
-        RC_HIP(hipEventRecord(c->sh[g].ev_comm, c->sh[g].cst));
+    RC_HIP(hipEventRecord(s.ev_comm, s.cst));
+    if (g == 0) {
+        // decode + LR check + filling on device 0 (n-sized, microseconds): main.cu:112-118, 140-155
+        RC_HIP(hipStreamWaitEvent(s.st, s.ev_comm, 0));
+        RC_SMX(smx_dev_finish_pair(p, s.keys, w, h, dminl, dminr, dminl - 100, (float)dminl, c->best, c->map, c->occ, c->fil, s.st));
+        const size_t fb = n * sizeof(float);
+        struct { void* dst; const void* src; size_t b; } copies[] = {
+            {out->best_l, c->best, fb}, {out->best_r, c->best + n, fb}, {out->dmap_l, c->map, fb}, {out->dmap_r, c->map + n, fb},
+            {out->mean_l, s.mean, n}, {out->mean_r, s.mean + n, n}, {out->occlusion, c->occ, fb}, {out->filled, c->fil, fb},
+        };
+        for (auto& cp : copies)
+            if (cp.dst) RC_HIP(hipMemcpyAsync(cp.dst, cp.src, cp.b, hipMemcpyDeviceToHost, s.st));
     }
-    // decode + LR check + filling on device 0 (n-sized, microseconds): main.cu:112-118, 140-155
-    RC_HIP(hipSetDevice(0));
-    hipStream_t st = c->sh[0].st;
-    RC_HIP(hipStreamWaitEvent(st, c->sh[0].ev_comm, 0));
-    RC_SMX(smx_dev_finish_pair(p, c->sh[0].keys, w, h, dminl, dminr, dminl - 100, (float)dminl, c->best, c->map, c->occ,
-                               c->fil, st));
-    const size_t fb = n * sizeof(float);
-    struct { void* dst; const void* src; size_t b; } copies[] = {
-        {out->best_l, c->best, fb}, {out->best_r, c->best + n, fb}, {out->dmap_l, c->map, fb}, {out->dmap_r, c->map + n, fb},
-        {out->mean_l, c->sh[0].mean, n}, {out->mean_r, c->sh[0].mean + n, n}, {out->occlusion, c->occ, fb}, {out->filled, c->fil, fb},
-    };
-    for (auto& cp : copies)
-        if (cp.dst) RC_HIP(hipMemcpyAsync(cp.dst, cp.src, cp.b, hipMemcpyDeviceToHost, st));
-    for (int g = 0; g < ngpu; ++g) {
-        RC_HIP(hipSetDevice(g));
-        RC_HIP(hipStreamSynchronize(c->sh[g].cst));
-        RC_HIP(hipStreamSynchronize(c->sh[g].st));
-        RC_SMX(smx_dev_agg_status(c->sh[g].ws));
-    }
-    RC_HIP(hipSetDevice(0));
+    RC_HIP(hipStreamSynchronize(s.cst));
+    RC_HIP(hipStreamSynchronize(s.st));
+    RC_SMX(smx_dev_agg_status(s.ws));
     return SMX_OK;
+}
+
+int smx_sharded_run(smx_sharded_ctx* c, const uint8_t* gray_l, const uint8_t* gray_r, int dminl, int dminr,
+                    const smx_pair_out* out) {
+    if (!c || !gray_l || !gray_r || !out)
+        return fail(SMX_E_ARG, "%s: %s (line %d)", "smx_sharded_run", "bad argument", __LINE__);
+    if (out->cost_l || out->cost_r || out->agg_l || out->agg_r)
+        return fail(SMX_E_ARG, "%s: %s (line %d)", "smx_sharded_run", "cost / agg outputs are not available in the sharded driver", __LINE__);
+    c->meet.failed.store(0);
+    for (int g = 0; g < c->ngpu; ++g)
+        c->workers[g]->post([=] { return shard_pair(c, g, gray_l, gray_r, dminl, dminr, out); });
+    int rc = SMX_OK;
+    for (int g = 0; g < c->ngpu; ++g) {
+        const int r = c->workers[g]->wait();
+        if (r != SMX_OK && rc == SMX_OK) {
+            rc = r;
+            snprintf(g_msg, sizeof(g_msg), "device %d: %s", g, c->workers[g]->msg);
+        }
+    }
+    return rc;
 }
 
 int smx_stereo_pair_sharded(const smx_params* p, const uint8_t* gray_l, const uint8_t* gray_r, int w, int h,

@@ -24,7 +24,7 @@ class PairPipeline:
     current stream, whatever device is current in the calling thread."""
 
     def __init__(self, w, h, size_d, dminl=None, dminr=0, s_begin=0, s_end=None, device="cuda:0",
-                 slices_in_flight=None, want_agg=False, params=None, max_ws_bytes=64 << 30):
+                 slices_in_flight=None, want_agg=False, params=None, max_ws_bytes=64 << 30, multi_kernel=False):
         self.lib = _lib.lib()
         self.w, self.h, self.size_d = int(w), int(h), int(size_d)
         self.n = self.w * self.h
@@ -36,11 +36,16 @@ class PairPipeline:
         self.params = params if params is not None else _lib.default_params()
         local = max(1, self.s_end - self.s_begin)
         sif = local if slices_in_flight is None else max(1, min(local, int(slices_in_flight)))
-        while sif > 1 and 2 * self.lib.smx_agg_workspace_bytes(self.w, self.h, sif) > max_ws_bytes:
+        # workspace of the path these parameters run (the fused walker: one plane per slice in flight); a forced
+        # multi-kernel path (smx_set_agg_path(1)) needs the radius-agnostic bound
+        multi = multi_kernel or self.params.radius > 9
+        need = (lambda n: self.lib.smx_agg_workspace_bytes(self.w, self.h, n)) if multi else \
+               (lambda n: self.lib.smx_agg_workspace_bytes_for(C.byref(self.params), self.w, self.h, n))
+        while sif > 1 and 2 * need(sif) > max_ws_bytes:
             sif = (sif + 1) // 2
         self.slices_in_flight = sif
         # pair calls (both views per launch) need twice the single-view workspace
-        self.ws_bytes = 2 * int(self.lib.smx_agg_workspace_bytes(self.w, self.h, sif))
+        self.ws_bytes = 2 * int(need(sif))
         dev = self.device
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         # keys[0] = left view, keys[1] = right view: one buffer so the shard merge is ONE all-reduce

@@ -9,12 +9,28 @@
 #include <vector>
 
 #include "costVolume.cuh"
+#include "filter.cuh"
 #include "guidedFilter.cuh"
 #include "integral.cuh"
 #include "occlusion.cuh"
 #include "rgb_to_grayscale.cuh"
 
 using std::vector;
+
+// ---- filter.cuh:6 (see the note there: a correct twin of the device path's mean, not the reference's broken body) --------
+void boxFilterOnCPU(unsigned char* image, unsigned char* mean, int width, int height) {
+    const int R = smx_config().params.radius, area = (2 * R + 1) * (2 * R + 1);
+    for (int y = 0; y < height; ++y)
+        for (int x = 0; x < width; ++x) {
+            float sum = 0.0f;
+            for (int ix = -R; ix <= R; ++ix)
+                for (int iy = -R; iy <= R; ++iy) {
+                    const int xx = x + ix, yy = y + iy;
+                    sum += (xx >= 0 && xx < width && yy >= 0 && yy < height) ? (float)image[(size_t)yy * width + xx] : 0.0f;
+                }
+            mean[(size_t)y * width + x] = (unsigned char)(int)(sum / area);
+        }
+}
 
 // ---- rgb_to_grayscale.cuh ------------------------------------------------------------------
 void sumArraysOnHost(unsigned char* image, unsigned char* gray, const int N, int channels) {

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "costVolume.cuh"
+#include "filter.cuh"
 #include "guidedFilter.cuh"
 #include "helpers.cuh"
 #include "integral.cuh"
@@ -39,6 +40,7 @@ void orc_gray(const orc_params* P, const uint8_t* rgb, int64_t n, int ch, uint8_
 void orc_cost_volume(const orc_params* P, const uint8_t* i1, const uint8_t* i2, float* cost, int w1, int w2, int h, int size_d, int dmin);
 void orc_integral(const float* in, float* out, int w, int h);
 void orc_init_wta(float* best, float* dmap, int64_t n);
+void orc_filter(const orc_params* P, const uint8_t* I, uint8_t* mean, float* var, int w, int h);
 void orc_guided_filter(const orc_params* P, const uint8_t* I, const float* cost, float* best, float* dmap, uint8_t* mean,
                        float* agg, int w, int h, int dmin, int s_begin, int s_end);
 void orc_detect_occlusion(const orc_params* P, float* dL, const float* dR, int dOcc, int w, int h);
@@ -86,6 +88,13 @@ int main(int argc, char** argv) {
     same("guided filter best", best.data(), obest.data(), n * 4);
     same("guided filter dmap", dmap.data(), odmap.data(), n * 4);
     same("guided filter mean", mean.data(), omean.data(), n);
+    {   // boxFilterOnCPU (filter.cuh:6) against the oracle's restatement of filter()'s mean
+        std::vector<unsigned char> bm(n), om(n);
+        std::vector<float> ov(n);
+        boxFilterOnCPU(g1.data(), bm.data(), w, h);
+        orc_filter(&P, g1.data(), om.data(), ov.data(), w, h);
+        same("boxFilterOnCPU", bm.data(), om.data(), n);
+    }
     std::vector<float> dr(n), occ(dmap), oocc(dmap);
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) dr[(size_t)y * w + x] = std::fabs(dmap[(size_t)y * w + (w - 1 - x)]);

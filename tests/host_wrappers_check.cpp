@@ -56,6 +56,10 @@ int main() {
         bool ok = check_errors(mean_ref.data(), mean.data(), n);
         ok = check_errors(var_ref.data(), var.data(), n) && ok;
         if (ok) std::cout << "ok filter" << std::endl; else ++failures;
+        // boxFilterOnCPU (filter.cuh:6): the CPU twin of the device path's mean
+        std::vector<unsigned char> mean_cpu(n);
+        boxFilterOnCPU(img.data(), mean_cpu.data(), w, h);
+        if (check_errors(mean_cpu.data(), mean.data(), n)) std::cout << "ok boxFilterOnCPU" << std::endl; else ++failures;
     }
     // detect_occlusion / fill_occlusion vs their twins
     {

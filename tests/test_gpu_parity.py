@@ -232,7 +232,7 @@ def _device_pair(Il, Ir, D, path=2, **kw):
     h, w = Il.shape
     dl = torch.from_numpy(Il).cuda()
     dr = torch.from_numpy(Ir).cuda()
-    pipe = PairPipeline(w, h, D, **kw)
+    pipe = PairPipeline(w, h, D, multi_kernel=(path == 1), **kw)     # (the multi-kernel path needs five planes per slice)
     smx.lib().smx_set_agg_path(path)
     try:
         pipe.run(dl, dr)
@@ -379,6 +379,12 @@ def test_fused_path_small_and_ragged(orc, path, w, h, D):
     r = _device_pair(Il, Ir, D, path=path, want_agg=True)
     for k in KEYS + ("aggl", "aggr"):
         _eq(r[k], want[k], k)
+    if path == 5:
+        # ... and the product's default layout: the comb-ordered q scratch (column order in the last strip), un-permuted by
+        # its own WTA pass -- what runs when the caller does not ask for the aggregated volume
+        r = _device_pair(Il, Ir, D, path=path, want_agg=False)
+        for k in KEYS:
+            _eq(r[k], want[k], "scratch layout " + k)
 
 
 @pytest.mark.parametrize("seed", range(10))
@@ -407,6 +413,9 @@ def test_comb_walker_fuzz(orc, seed):
     r = _device_pair(Il, Ir, D, path=5, dminl=dminl, dminr=dminr, want_agg=True, params=p)
     for k in KEYS + ("aggl", "aggr"):
         _eq(r[k], want[k], f"seed {seed} w={w} h={h} D={D} {k}")
+    r = _device_pair(Il, Ir, D, path=5, dminl=dminl, dminr=dminr, want_agg=False, params=p)     # the comb-ordered scratch + k_v5_wta
+    for k in KEYS:
+        _eq(r[k], want[k], f"seed {seed} w={w} h={h} D={D} scratch layout {k}")
 
 
 @pytest.mark.parametrize("radius,w,h", [(0, 128, 52), (0, 129, 53), (4, 64, 26), (4, 65, 78), (4, 192, 27), (4, 64, 16), (9, 130, 33), (1, 70, 48)])

@@ -22,7 +22,7 @@ REFERENCE_SIGNATURES = {   # reference header -> host function names it must sti
                          "pixelSousOnCPU", "pixelAddOnCPU", "pixelDivOnCPU", "guided_filter_onCpu"],
     "integral.cuh": ["integral", "integralOnCPU"],
     "occlusion.cuh": ["detect_occlusion", "fill_occlusion", "detect_occlusionOnCPU", "fill_occlusionOnCPU"],
-    "filter.cuh": ["filter"],
+    "filter.cuh": ["filter", "boxFilterOnCPU"],
     "helpers.cuh": ["check_errors"],
     "winner_take_all.cuh": ["wta_pack"],
 }
@@ -118,7 +118,7 @@ def test_reference_signature_wrappers_on_the_gpu(binary, tmp_path):
                   os.path.join(HOST, "stages.cpp")])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
-    for name in ("check_errors", "integral", "filter", "occlusion"):
+    for name in ("check_errors", "integral", "filter", "boxFilterOnCPU", "occlusion"):
         assert "ok " + name in r.stdout, r.stdout
 
 

@@ -25,21 +25,24 @@ for it in range(N):
     p.radius = R
     Il, Ir = synth.gen_pair(w, h, D, int(rng.integers(1, 1 << 30)))
     ref = oracle.stereo_pair(Il, Ir, D, want_agg=True, params=oracle.Params.from_buffer_copy(bytes(p)))
-    pipe = PairPipeline(w, h, D, want_agg=True, params=p, slices_in_flight=sif)
     dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
-    pipe.run(dl, dr)
-    got = pipe.results()
     ok = True
-    for k in ("meanl", "meanr", "dmapl", "dmapr", "bestl", "bestr", "occlusion", "filled", "aggl", "aggr"):
-        if k not in got or k not in ref:
-            continue
-        a, b = np.asarray(got[k]), np.asarray(ref[k]).reshape(np.asarray(got[k]).shape)
-        neq = (a.view(np.uint32) != b.view(np.uint32)) if a.dtype == np.float32 else (a != b)
-        if a.dtype == np.float32:
-            neq &= ~(np.isnan(a) & np.isnan(b))
-        if neq.any():
-            ok = False
-            print(f"  MISMATCH {k}: {int(neq.sum())} of {neq.size}")
+    # both q layouts: the caller's [z][y][x] volume, and the product's default (own scratch -- comb-ordered where the comb
+    # walker runs -- with its own WTA pass)
+    for want_agg in (True, False):
+        pipe = PairPipeline(w, h, D, want_agg=want_agg, params=p, slices_in_flight=sif)
+        pipe.run(dl, dr)
+        got = pipe.results()
+        for k in ("meanl", "meanr", "dmapl", "dmapr", "bestl", "bestr", "occlusion", "filled", "aggl", "aggr"):
+            if k not in got or k not in ref:
+                continue
+            a, b = np.asarray(got[k]), np.asarray(ref[k]).reshape(np.asarray(got[k]).shape)
+            neq = (a.view(np.uint32) != b.view(np.uint32)) if a.dtype == np.float32 else (a != b)
+            if a.dtype == np.float32:
+                neq &= ~(np.isnan(a) & np.isnan(b))
+            if neq.any():
+                ok = False
+                print(f"  MISMATCH {k} (want_agg={want_agg}): {int(neq.sum())} of {neq.size}")
     print(f"R={R} {w}x{h} D={D} sif={sif}: {'OK' if ok else 'MISMATCH'}", flush=True)
     bad += not ok
 print("bad", bad)

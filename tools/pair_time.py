@@ -16,7 +16,8 @@ else:
     w, h, D = synth.SHAPES[wl]
 Il, Ir = synth.gen_pair(w, h, D, synth.SEEDS.get(wl, 1))
 N = max(10, int(300 * (1242 * 375 * 192) / (float(w) * h * D)))
-pipe = PairPipeline(w, h, D)
+sif = int(os.environ["SMX_SIF"]) if "SMX_SIF" in os.environ else None       # slices per walker launch (A/B runs)
+pipe = PairPipeline(w, h, D, slices_in_flight=sif)
 dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
 smx.check(smx.lib().smx_set_agg_path(path))
 def step():
@@ -30,4 +31,4 @@ for _ in range(reps):
     torch.cuda.synchronize()
     out.append((time.perf_counter() - t0) / N * 1e3)
 pipe.check_status()
-print(wl, "path", path, "ms/pair", " ".join(f"{v:.4f}" for v in out), flush=True)
+print(wl, "path", path, "chunk", pipe.last_chunk(), "ms/pair", " ".join(f"{v:.4f}" for v in out), flush=True)
