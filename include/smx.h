@@ -211,6 +211,12 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
  * waits cannot deadlock (every wait is for a work item with a smaller ticket), so this only fires
  * if the GPU is taken away mid-launch; the host-pointer wrappers call it for you. */
 int smx_dev_agg_status(const void* d_workspace);
+/* Materialised cost volumes (d_cost != NULL) and radius 9: the comb walker loads the costs and checks that each is +0 or a
+ * normal number in [2^-60, 2^60] -- what its exactness argument covers (costVolume.cu:187 produces nothing else).  A
+ * call with other values (negative, -0, denormal, infinite, NaN) is still answered bit-exactly: the ring walker is queued
+ * behind the comb walker and redoes the chunk on the device when the check fired.  This reports, after synchronising the
+ * stream, whether that happened in the last call that used d_workspace (the call then cost about 2.5 x). */
+int smx_dev_agg_fallback(const void* d_workspace, int* ring_walker_reran);
 
 /* Aggregation implementation of the calling THREAD's smx_dev_* and host-pointer stage calls (a persistent
  * context carries its own, smx_ctx_set_agg_path; it starts with the creating thread's):

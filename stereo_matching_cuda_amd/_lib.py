@@ -85,6 +85,7 @@ SIGNATURES = {
     "smx_dev_aggregate_wta": (_i, [_PP, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "smx_dev_aggregate_wta_pair": (_i, [_PP, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "smx_dev_agg_status": (_i, [_vp]),
+    "smx_dev_agg_fallback": (_i, [_vp, C.POINTER(_i)]),
     "smx_dev_init_keys": (_i, [_vp, _i64, _vp]),
     "smx_dev_apply_keys": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
     "smx_dev_init_wta": (_i, [_vp, _vp, _i64, _vp]),

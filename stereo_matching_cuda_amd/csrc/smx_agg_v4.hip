@@ -96,6 +96,7 @@ struct Args {
     unsigned* flags;      // [sv][K]  published-record counters (zeroed before every launch)
     unsigned* ticket;     // work-item counter              (zeroed before every launch)
     unsigned* status;     // != 0: a flag wait timed out (results invalid)
+    const unsigned* only_if;   // != NULL: the launch does nothing unless this word is nonzero (the queued fall-back behind the comb walker)
     CostConst cc;
 };
 
@@ -428,6 +429,7 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
         c = (4 * (wave - QW0) + (l >> 4)) * 4;
     };
 
+    if (A.only_if && flag_load(const_cast<unsigned*>(A.only_if)) == 0u) return;     // (uniform: every thread reads the same word)
     if (tid == 0) s_item = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
         wg_barrier();
@@ -1213,11 +1215,16 @@ __global__ __launch_bounds__(NT, 2 * WG_PER_CU) void k_v4_walk(Args A) {
 struct WtaArgs {
     const float* q[2];
     int64_t* keys[2];
+    const unsigned* gate;     // != NULL: the pass runs only if (*gate != 0) == gate_nonzero (which walker's q planes are valid)
+    int gate_nonzero;
 };
+__device__ __forceinline__ bool wta_gate_closed(const unsigned* gate, int gate_nonzero) {
+    return gate && (int)(flag_load(const_cast<unsigned*>(gate)) != 0u) != gate_nonzero;
+}
 
 __global__ __launch_bounds__(256) void k_v4_wta(WtaArgs wa, size_t n, int count, int slice0) {
     const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (id >= n) return;
+    if (id >= n || wta_gate_closed(wa.gate, wa.gate_nonzero)) return;
     const float* __restrict__ q = wa.q[blockIdx.y] + id;
     int64_t* keys = wa.keys[blockIdx.y];
     int64_t key = keys[id];
@@ -1243,7 +1250,7 @@ __global__ __launch_bounds__(256) void k_v4_wta(WtaArgs wa, size_t n, int count,
 // grid (ceil(n/512), nviews)
 __global__ __launch_bounds__(256) void k_v4_wta2(WtaArgs wa, size_t n, int count, int slice0) {
     const size_t id = ((size_t)blockIdx.x * 256 + threadIdx.x) * 2;
-    if (id >= n) return;
+    if (id >= n || wta_gate_closed(wa.gate, wa.gate_nonzero)) return;
     const float* __restrict__ q = wa.q[blockIdx.y] + id;
     int64_t* keys = wa.keys[blockIdx.y];
     int64_t k0 = keys[id], k1 = keys[id + 1];
@@ -1300,9 +1307,8 @@ bool v4_supported(const smx_params* p) { return p->radius >= 0 && p->radius <= v
 
 constexpr size_t V4_CTRL_BYTES = 256;   // ticket (zeroed with the flags before every launch)
 
-static size_t v4_flag_bytes(const V4Layout& L, int nsv) {
-    return align_up(V4_CTRL_BYTES + (size_t)nsv * L.K * sizeof(unsigned), 256);
-}
+static size_t v4_flag_bytes_k(int K, int nsv) { return align_up(V4_CTRL_BYTES + (size_t)nsv * K * sizeof(unsigned), 256); }
+static size_t v4_flag_bytes(const V4Layout& L, int nsv) { return v4_flag_bytes_k(L.K, nsv); }
 
 // bytes for ONE view with `nslices` slices in flight (q planes included)
 size_t v4_workspace_bytes(int w, int h, int nslices) {
@@ -1360,10 +1366,11 @@ extern "C" __attribute__((visibility("default"))) int smx_debug_read_stamps(unsi
 }
 #endif
 
-// status word of the last fused aggregation that used this workspace (0 = ok)
-int v4_read_status(const void* d_ws, unsigned* out) {
+// status words of the last fused aggregation that used this workspace: [0] != 0: a hand-off wait timed out;
+// [1] != 0: the comb walker met cost values outside its exactness argument and the queued ring walker redid the chunk
+int v4_read_status(const void* d_ws, unsigned* out, int nwords) {
     const char* base = (const char*)align_up((size_t)d_ws, 256);
-    SMX_HIP(hipMemcpy(out, base, sizeof(unsigned), hipMemcpyDeviceToHost));
+    SMX_HIP(hipMemcpy(out, base, sizeof(unsigned) * (size_t)nwords, hipMemcpyDeviceToHost));
     return SMX_OK;
 }
 
@@ -1394,16 +1401,28 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     // descriptor with 32-bit offsets, 0x80000000 marking "outside": the whole region must stay below 2 GiB
     // (v5_fix_bytes: the same terms the carving below uses).
     const bool v5_fits = v5_fix_bytes(w, h, nviews) < 0x80000000ull;
-    const bool use_v5 = opt.walker != 4 && !use_cost && v5_supported(p) && v5_fits;
+    // Materialised cost volumes (the reference's calling convention, guidedFilter.cu:198-200) run on the comb walker too
+    // (round 5): its cost wave loads the costs and CHECKS them -- +0 or a normal number in [2^-60, 2^60] is what its exactness
+    // argument covers.  A violation cannot come back to the host of an asynchronous call, so the ring walker, which takes
+    // any input, is queued behind it with a device-side gate (`only_if`): it does nothing unless the comb walker raised the
+    // second status word, and the two WTA passes are gated the other way round.  Cost: two empty launches and a memset.
+    const bool use_v5 = opt.walker != 4 && v5_fits &&
+                        (use_cost ? v5_supported_cost(p) && (size_t)w * h >= 4 : v5_supported(p));
+    const bool fallback4 = use_v5 && use_cost;
     if (opt.walker == 5 && !use_v5)
-        return fail(SMX_E_ARG, "aggregate_v4: the comb walker does not apply (radius 9, costs built from the images, default-like "
-                               "cost parameters, planes of %d x %d within its 2 GiB descriptor: %s)", w, h, v5_fits ? "yes" : "no");
+        return fail(SMX_E_ARG, "aggregate_v4: the comb walker does not apply (radius 9, eps >= 1, default-like cost parameters where "
+                               "the costs are built from the images, planes of %d x %d within its 2 GiB descriptor: %s)", w, h,
+                    v5_fits ? "yes" : "no");
     if (info) { *info = AggInfo(); info->walker_used = use_v5 ? 5 : 4; }
+    const V4Layout L4 = L;      // the ring walker's geometry (the queued fall-back uses it)
     if (use_v5) {
         L.K = v5::strips(w);
         L.NI = v5::bands(h);
         L.sv_hand = v5::sv_hand_floats(h);
     }
+    // records and flags are shared by the two walkers of a call with a queued fall-back: the larger of each
+    const size_t sv_hand_c = fallback4 && L4.sv_hand > L.sv_hand ? L4.sv_hand : L.sv_hand;
+    const int K_c = fallback4 && L4.K > L.K ? L4.K : L.K;
     // every plane is addressed through 32-bit buffer offsets, with 0x80000000 as "outside the image"
     if ((size_t)h * ((size_t)w + 2 * v4::PADX) * 8 >= 0x80000000ull)
         return fail(SMX_E_ARG, "aggregate_v4: an image plane of %d x %d exceeds 2 GiB", w, h);
@@ -1448,8 +1467,8 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     const bool own_q = !(d_agg && d_agg[0]);
     // (the comb walker's own q planes are comb-ordered: K * OWS >= w columns per row)
     const size_t qplane = use_v5 && own_q ? (size_t)L.K * h * v5::OWS : L.plane;
-    const size_t per_sv = (own_q ? align_up(qplane * 4, 256) : 0) + L.sv_hand * 4 +
-                          (size_t)L.K * sizeof(unsigned);
+    const size_t per_sv = (own_q ? align_up(qplane * 4, 256) : 0) + sv_hand_c * 4 +
+                          (size_t)K_c * sizeof(unsigned);
     size_t fit = avail > 8 * 256 + V4_CTRL_BYTES ? (avail - 8 * 256 - V4_CTRL_BYTES) / (per_sv * nviews) : 0;
     if (oom || (fit < 1 && total > 0))
         return fail(SMX_E_WS, "aggregate_v4: workspace %zu B too small (need >= %zu B per view)",
@@ -1462,8 +1481,8 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     float* qbuf[2] = {nullptr, nullptr};
     if (own_q)
         for (int v = 0; v < nviews; ++v) qbuf[v] = (float*)carve((size_t)chunk * align_up(qplane * 4, 256));
-    v4::f2* hand = (v4::f2*)carve((size_t)nsv_max * L.sv_hand * 4);
-    char* ctrl = (char*)carve(v4_flag_bytes(L, nsv_max));
+    v4::f2* hand = (v4::f2*)carve((size_t)nsv_max * sv_hand_c * 4);
+    char* ctrl = (char*)carve(v4_flag_bytes_k(K_c, nsv_max));
     if (oom) return fail(SMX_E_WS, "aggregate_v4: workspace carve overflow");
     int nl = 0, rc;
 
@@ -1473,7 +1492,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     pa.FG[0] = FG[0]; pa.FG[1] = FG[1];
     const int nimg = pa.I[1] ? 2 : 1;
     pa.zero[0] = status; pa.nzero[0] = 64;
-    pa.zero[1] = (unsigned*)ctrl; pa.nzero[1] = (unsigned)(v4_flag_bytes(L, nsv_max) / 4);
+    pa.zero[1] = (unsigned*)ctrl; pa.nzero[1] = (unsigned)(v4_flag_bytes_k(K_c, nsv_max) / 4);
     hipLaunchKernelGGL(v4::k_v4_prep, dim3(cdivu4(w + 2 * v4::PADX, 256), h, nimg), dim3(256), 0, st, pa, w, h);
     SMX_HIP(hipGetLastError());
     ++nl;
@@ -1541,7 +1560,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         a.hand = hand;
         a.ticket = (unsigned*)ctrl; a.status = status;
         a.flags = (unsigned*)(ctrl + V4_CTRL_BYTES);
-        if (s0 != s_begin) SMX_HIP(hipMemsetAsync(ctrl, 0, v4_flag_bytes(L, a.nsv), st));   // (first chunk: cleared by k_v4_prep)
+        if (s0 != s_begin) SMX_HIP(hipMemsetAsync(ctrl, 0, v4_flag_bytes_k(K_c, a.nsv), st));   // (first chunk: cleared by k_v4_prep)
         if (use_v5) {
             v5::Args b;
             memset(&b, 0, sizeof(b));
@@ -1558,6 +1577,10 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             b.w = w; b.h = h; b.K = L.K; b.NI = L.NI;
             b.nslices = a.nslices; b.nsv = a.nsv; b.nitems = a.nitems;
             b.hand = (float*)hand; b.flags = a.flags; b.ticket = a.ticket; b.status = a.status;
+            b.src_cost = use_cost ? 1 : 0;
+            b.cost_plane = L.plane;
+            b.bad = status + 1;
+            for (int v = 0; v < 2; ++v) b.cost[v] = a.v[v < nviews ? v : 0].cost;
             b.cc = a.cc;
             {
                 const _Float16 hc = (_Float16)a.cc.th_color, hg = (_Float16)a.cc.th_grad;
@@ -1585,6 +1608,16 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             b.qperm = own_q ? 1 : 0;
             b.q_plane = qplane;
             rc = v5_launch(b, st);
+            if (!rc && fallback4) {
+                // the queued ring walker (does nothing unless status[1] was raised): its own geometry, fresh tickets and flags
+                SMX_HIP(hipMemsetAsync(ctrl, 0, v4_flag_bytes_k(K_c, a.nsv), st));
+                v4::Args a4 = a;
+                a4.K = L4.K; a4.NI = L4.NI;
+                a4.nitems = a4.nsv * L4.K;
+                a4.only_if = status + 1;
+                rc = fast ? launch_walk4<v4::SRC_COST, true>(a4, st) : launch_walk4<v4::SRC_COST, false>(a4, st);
+                nl += 2;
+            }
         } else if (fast) rc = use_cost ? launch_walk4<v4::SRC_COST, true>(a, st) : launch_walk4<v4::SRC_IMG, true>(a, st);
         else rc = use_cost ? launch_walk4<v4::SRC_COST, false>(a, st) : launch_walk4<v4::SRC_IMG, false>(a, st);
         if (rc) return rc;
@@ -1592,8 +1625,17 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         stage_mark(ST_WALK, st);
         bool al8 = L.plane % 2 == 0;
         for (int v = 0; v < nviews; ++v) al8 = al8 && ((uintptr_t)wa.q[v] & 7) == 0;
+        wa.gate = nullptr; wa.gate_nonzero = 0;
         if (use_v5 && own_q) {
-            if ((rc = v5_wta_launch(nviews, wa.q, wa.keys, w, h, cnt, s0, st))) return rc;
+            if ((rc = v5_wta_launch(nviews, wa.q, wa.keys, w, h, cnt, s0, fallback4 ? status + 1 : nullptr, st))) return rc;
+            if (fallback4) {
+                // ... and the WTA over the ring walker's planes ([slice][h][w] at the start of the same buffers), if it ran
+                wa.gate = status + 1; wa.gate_nonzero = 1;
+                if (al8) hipLaunchKernelGGL(v4::k_v4_wta2, dim3(cdivu4((int64_t)L.plane, 512), nviews), dim3(256), 0, st, wa, L.plane, cnt, s0);
+                else hipLaunchKernelGGL(v4::k_v4_wta, dim3(cdivu4((int64_t)L.plane, 256), nviews), dim3(256), 0, st, wa, L.plane, cnt, s0);
+                SMX_HIP(hipGetLastError());
+                ++nl;
+            }
         } else if (al8)
             hipLaunchKernelGGL(v4::k_v4_wta2, dim3(cdivu4((int64_t)L.plane, 512), nviews), dim3(256), 0, st, wa,
                                L.plane, cnt, s0);

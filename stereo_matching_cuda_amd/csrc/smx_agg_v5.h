@@ -30,6 +30,12 @@ struct Args {
     unsigned o_i2p[2];    // u32x4 [K][NI][CLP] + u32 [K][NI][CLP] behind it: image values (fp16 pairs) of the ten q rows of band ib at the q column OWS k - 19 + 19 il + rho
     // out, per view: qperm != 0: comb-ordered scratch [slice][K][h][OWS], column OWS k + 19 (il-1) + rho at
     // [(L-1) rho + il - 1] (a wave stores one contiguous run; read back by k_v5_wta); else the caller's [slice][h][w]
+    // materialised cost volumes (src_cost != 0): slice s of view v at cost[v] + s * cost_plane, [h][w] each (the reference's
+    // calling convention, guidedFilter.cu:198); else the costs are built from the image planes
+    const float* cost[2];
+    size_t cost_plane;    // floats per slice of a cost volume (w * h)
+    int src_cost;
+    unsigned* bad;        // src_cost: raised when a cost value falls outside what the exactness argument covers
     float* q[2];
     int qperm;
     size_t q_plane;       // floats per slice of q
@@ -56,12 +62,14 @@ inline size_t sv_hand_floats(int h) { return (size_t)2 * records(h) * REC_U * 4;
 // kernel then needs no exact-division check in stage 1) nor any sum non-finite: every nonzero truncated cost
 // term >= 2^-60, eps >= 1
 bool v5_supported(const smx_params* p);
+bool v5_supported_cost(const smx_params* p);     // the same for materialised cost volumes (values checked in the kernel)
 int v5_launch(const v5::Args& a, hipStream_t st);
 // comb-ordered guidance planes of one call: G (mean_I, 1/(var+eps)) [h][w] and the image planes FG -> g1p, i2p
 int v5_perm_launch(int nviews, const aggdev::f2* const* G, const aggdev::fg_t* const* FG, aggdev::f2* const* g1p,
                    unsigned* const* i2p, int w, int h, hipStream_t st);
 // packed-key WTA over `count` comb-ordered q planes (slice slice0 ..) of `nviews` views -> keys [h][w]
+// (skip_if != NULL: a device word; the pass does nothing when it is nonzero)
 int v5_wta_launch(int nviews, const float* const* q, int64_t* const* keys, int w, int h, int count, int slice0,
-                  hipStream_t st);
+                  const unsigned* skip_if, hipStream_t st);
 
 }  // namespace smx

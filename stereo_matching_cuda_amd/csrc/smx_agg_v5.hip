@@ -383,24 +383,51 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 const unsigned rowb = (unsigned)row * fgw4;
                 cw_rowb[r] = (unsigned)opaque((int)rowb);       // (opaque: computed here, once per item, not where the band loop uses them)
                 cw_a1[r] = (unsigned)opaque((int)((unsigned)(min(max(base1 + col, -PADX), w) + PADX) * 4u + rowb));
-                cw_a2[r] = (unsigned)opaque((int)((unsigned)(min(max(base1 + col + d, -PADX), w) + PADX) * 4u + rowb));
+                // the partner cell in the other view's plane -- or, for a materialised cost volume (A.src_cost), the byte offset
+                // of the quad in a slice plane of the volume, band term excluded (can be -4: column -1 of row 0 in strip 0)
+                cw_a2[r] = A.src_cost ? (unsigned)opaque((row * w + base1 + col) * 4)
+                                      : (unsigned)opaque((int)((unsigned)(min(max(base1 + col + d, -PADX), w) + PADX) * 4u + rowb));
                 cw_t[r] = (unsigned)opaque((int)(on ? (unsigned)(row * RS + col) * 4u : (unsigned)SW * 4u));      // (lanes without a quad: a padding column)
                 unsigned m = 0;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) m |= (base1 + col + j >= 0 && base1 + col + j < w) ? 1u << j : 0u;
-                cw_m[r] = (unsigned)opaque((int)m);
+                cw_m[r] = (unsigned)opaque((int)(m | ((unsigned)row << 8)));     // (bits 8..: the tile row of the quad)
             }
         }
+        // ---- materialised cost volumes (the reference's calling convention, guidedFilter.cu:198-200: slice s of view v at
+        // cost[v] + s * w * h): the cost wave LOADS the four costs of a quad instead of evaluating them; I p as before.
+        // One descriptor per item over the slice plane.  A quad starts at column OWS k - 1 + 4 j: unaligned 16-byte loads (4-byte
+        // aligned).  Edge items clamp the quad into the plane and shift the lanes of the vector back (cost_lin).
+        // What the exactness argument at the top of this file needs from the values -- +0 or a normal number in [2^-60, 2^60],
+        // so that no window sum is negative, -0, tiny or non-finite -- is CHECKED here on every cost inside the image: the running
+        // unsigned maximum of the bit patterns and minimum of (pattern - 1) per lane, compared once per item; a violation raises
+        // the second status word, and the host has queued the ring walker behind this kernel to redo the chunk if it is set.
+        rsrc_t r_c = r_q;
+        unsigned c_max = 0u, c_min1 = 0xffffffffu;
+        const unsigned plane4 = (unsigned)(A.cost_plane * 4);
+        if constexpr (ROLE == ROLE_COST) {
+            if (A.src_cost) r_c = mk_rsrc(A.cost[view] + (size_t)slice * A.cost_plane, A.cost_plane * 4);
+        }
+        // edge items: byte offset of quad r of band ib clamped into the slice plane, and by how many elements it was moved
+        auto cost_lin = [&](int ib, int r, int& linc4, int& sh) {
+            const int row = (int)(cw_m[r] >> 8);
+            const int e = max(0, BH * ib + row - (h - 1));                  // rows below the image read the last image row
+            const int lin4 = (int)cw_a2[r] + (BH * ib - e) * (int)w4;
+            linc4 = min(max(lin4, 0), (int)plane4 - 16);
+            sh = (lin4 - linc4) >> 2;
+        };
         // (loading a band ahead of its slot -- 56 registers through the slot -- spills and is slower: measured)
         u4 cw_ra[CWN], cw_rb[CWN];
-        auto cw_issue = [&](int ib, auto R0c) {
+        auto cw_issue = [&](int ib, auto R0c, auto EDGEc, auto SRCc) {
             constexpr int R0 = decltype(R0c)::value, R1 = R0 + NRB < CWN ? R0 + NRB : CWN;
+            constexpr bool EDGE = decltype(EDGEc)::value, SRCC = decltype(SRCc)::value;
             const unsigned bandb = (unsigned)(BH * ib) * fgw4, ymaxb = (unsigned)(h - 1) * fgw4;
             if (BH * ib + BH <= h) {
 #pragma unroll
                 for (int r = R0; r < R1; ++r) {
                     cw_ra[r] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a1[r], o_fg1 + (int)bandb, 0));
-                    cw_rb[r] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a2[r], o_fg2 + (int)bandb, 0));
+                    if constexpr (!SRCC)
+                        cw_rb[r] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a2[r], o_fg2 + (int)bandb, 0));
                 }
             } else {
                 // rows behind the image read the last image row (every load is issued; their cells become -0 in cw_finish)
@@ -408,33 +435,71 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 for (int r = R0; r < R1; ++r) {
                     const int yadj = min((int)bandb, (int)ymaxb - (int)cw_rowb[r]);
                     cw_ra[r] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a1[r] + yadj, o_fg1, 0));
-                    cw_rb[r] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a2[r] + yadj, o_fg2, 0));
+                    if constexpr (!SRCC)
+                        cw_rb[r] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)cw_a2[r] + yadj, o_fg2, 0));
+                }
+            }
+            if constexpr (SRCC) {
+#pragma unroll
+                for (int r = R0; r < R1; ++r) {
+                    if constexpr (EDGE) {
+                        int linc4, sh;
+                        cost_lin(ib, r, linc4, sh);
+                        cw_rb[r] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_c, linc4, 0, 0));
+                    } else {
+                        cw_rb[r] = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_c, (int)cw_a2[r], BH * ib * (int)w4, 0));
+                    }
                 }
             }
         };
-        auto cw_finish = [&](int ib, float* dst, auto R0c, auto EDGEc) {
-            constexpr bool EDGE = decltype(EDGEc)::value;
+        auto cw_finish = [&](int ib, float* dst, auto R0c, auto EDGEc, auto SRCc) {
+            constexpr bool EDGE = decltype(EDGEc)::value, SRCC = decltype(SRCc)::value;
             constexpr int R0 = decltype(R0c)::value, R1 = R0 + NRB < CWN ? R0 + NRB : CWN;
             const unsigned bandb = (unsigned)(BH * ib) * fgw4, ymaxb = (unsigned)(h - 1) * fgw4;
             char* const dstb = (char*)dst;
 #pragma unroll
             for (int r = R0; r < R1; ++r) {
-                const unsigned q1[4] = {cw_ra[r].x, cw_ra[r].y, cw_ra[r].z, cw_ra[r].w}, q2[4] = {cw_rb[r].x, cw_rb[r].y, cw_rb[r].z, cw_rb[r].w};
-                f4 t1, t2, ip;
+                const unsigned q1[4] = {cw_ra[r].x, cw_ra[r].y, cw_ra[r].z, cw_ra[r].w};
+                unsigned q2[4] = {cw_rb[r].x, cw_rb[r].y, cw_rb[r].z, cw_rb[r].w};
+                f4 pp, ip;
+                if constexpr (!SRCC) {
+                    f4 t1, t2;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const unsigned m = cost_trunc_h2(q1[j], q2[j], A.th2);
-                    t1[j] = mix_mul_lo(m, cc.oma);
-                    t2[j] = mix_mul_hi(m, cc.alpha);
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned m = cost_trunc_h2(q1[j], q2[j], A.th2);
+                        t1[j] = mix_mul_lo(m, cc.oma);
+                        t2[j] = mix_mul_hi(m, cc.alpha);
+                    }
+                    pp = t1 + t2;
+                } else {
+                    if constexpr (EDGE) {
+                        // the quad was loaded `sh` elements away from where it belongs (clamped into the plane): element j of the
+                        // quad is element j + sh of the vector; positions that fall off are outside the image (masked below)
+                        int linc4, sh;
+                        cost_lin(ib, r, linc4, sh);
+                        if (sh == -1) { q2[3] = q2[2]; q2[2] = q2[1]; q2[1] = q2[0]; }
+                        else if (sh == 1) { q2[0] = q2[1]; q2[1] = q2[2]; q2[2] = q2[3]; }
+                        else if (sh == 2) { q2[0] = q2[2]; q2[1] = q2[3]; }
+                        else if (sh == 3) { q2[0] = q2[3]; }
+                        const bool rowok = bandb + cw_rowb[r] <= ymaxb;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (!(rowok && (((cw_m[r] & 0xffu) >> j) & 1u) != 0u)) q2[j] = 0u;   // (outside the image: not checked, replaced by -0 below)
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        c_max = max(c_max, q2[j]);
+                        c_min1 = min(c_min1, q2[j] - 1u);
+                        pp[j] = __builtin_bit_cast(float, q2[j]);
+                    }
                 }
-                f4 pp = t1 + t2;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ip[j] = mix_mul_lo_v(q1[j], pp[j]);
+                for (int j = 0; j < 4; ++j) ip[j] = mix_mul_lo_v(q1[j], pp[j]);     // I p (guidedFilter.cu:200 pixelMultOnGPU)
                 if constexpr (EDGE) {
                     const bool rowok = bandb + cw_rowb[r] <= ymaxb;
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        if (!(rowok && ((cw_m[r] >> j) & 1u))) { pp[j] = -0.0f; ip[j] = -0.0f; }
+                        if (!(rowok && (((cw_m[r] & 0xffu) >> j) & 1u) != 0u)) { pp[j] = -0.0f; ip[j] = -0.0f; }
                 }
                 *(f4*)(dstb + cw_t[r]) = pp;
                 *(f4*)(dstb + cw_t[r] + P1 * 4) = ip;
@@ -442,16 +507,20 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         };
         auto eval_band_p = [&](int ib, float* dst) {
             static_assert(2 * NRB >= CWN, "two batches");
-            auto run = [&](auto EDGEc) {
-                cw_issue(ib, std::integral_constant<int, 0>{});
-                cw_finish(ib, dst, std::integral_constant<int, 0>{}, EDGEc);
+            auto run = [&](auto EDGEc, auto SRCc) {
+                cw_issue(ib, std::integral_constant<int, 0>{}, EDGEc, SRCc);
+                cw_finish(ib, dst, std::integral_constant<int, 0>{}, EDGEc, SRCc);
                 if constexpr (NRB < CWN) {
-                    cw_issue(ib, std::integral_constant<int, NRB>{});
-                    cw_finish(ib, dst, std::integral_constant<int, NRB>{}, EDGEc);
+                    cw_issue(ib, std::integral_constant<int, NRB>{}, EDGEc, SRCc);
+                    cw_finish(ib, dst, std::integral_constant<int, NRB>{}, EDGEc, SRCc);
                 }
             };
-            // (two versions of the whole band: the interior one has no trace of the edge handling)
-            if (xedge || BH * ib + BH > h) run(std::true_type{}); else { V5_MARK("cost begin"); run(std::false_type{}); V5_MARK("cost end"); }
+            // (versions of the whole band: the interior one has no trace of the edge handling, the cost-volume one none of the
+            // cost evaluation)
+            const bool edge = xedge || BH * ib + BH > h;
+            if (A.src_cost) { if (edge) run(std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{}); }
+            else if (edge) run(std::true_type{}, std::false_type{});
+            else { V5_MARK("cost begin"); run(std::false_type{}, std::false_type{}); V5_MARK("cost end"); }
         };
         // guidance of the output rows of iteration ib: FEW, WIDE loads -- a vector-memory instruction costs its wave and the CU's
         // address path the same whatever its width, and ten 8-byte loads per stage-1 wave and band were 700-1000 cycles of its
@@ -909,8 +978,15 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             slot(std::integral_constant<int, 0>{}, sl);
             if (sl + 1 < NI) slot(std::integral_constant<int, 1>{}, sl + 1);
         }
+        if constexpr (ROLE == ROLE_COST) {
+            // a cost of the volume outside {+0} U [2^-60, 2^60] (negative, -0, denormal, tiny, huge, infinite, NaN): this
+            // kernel's results for the chunk do not count (smx_agg_v4.hip has queued the ring walker behind it)
+            if (A.src_cost && __builtin_amdgcn_ballot_w64(c_max > 0x5d800000u || c_min1 < 0x21800000u - 1u) != 0 && lane == 0)
+                flag_store(A.bad, 1u);
+        }
         };
         if (tid == 0) { s_x1 = 0u; s_peek[0] = 0u; s_peek[1] = 0u; }   // (ordered before the first use by the barrier at the top of the first band)
+        // (the cost wave's verdict on a materialised cost volume is raised inside item_body, below the slot loop)
         if (wave < NS1) item_body(std::integral_constant<int, ROLE_S1>{});
         else if (wave < 2 * NS1) item_body(std::integral_constant<int, ROLE_S2>{});
         else if (wave == 2 * NS1) item_body(std::integral_constant<int, ROLE_SCAN>{});
@@ -981,6 +1057,7 @@ __global__ __launch_bounds__(CLP) void k_v5_perm(PermArgs pa, int w, int h, int 
 struct Wta5Args {
     const float* q[2];
     int64_t* keys[2];
+    const unsigned* skip_if;      // != NULL: the pass does nothing if this word is nonzero (the comb walker's planes do not count)
 };
 // Four elements per lane, 16-byte loads: a strip row is OWS = 152 floats, so a plane is a whole number of quads, and the
 // planes are carved 256-byte aligned (aggregate_v4)
@@ -989,7 +1066,7 @@ __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K
     constexpr int EPL = 4;
     const size_t np = (size_t)K * h * OWS;
     const size_t e0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * EPL;
-    if (e0 >= np) return;
+    if (e0 >= np || (wa.skip_if && flag_load(const_cast<unsigned*>(wa.skip_if)) != 0u)) return;
     const float* __restrict__ q = wa.q[blockIdx.y] + e0;
     int64_t* const keys = wa.keys[blockIdx.y];
     // the pixels of this lane's elements (once per call)
@@ -1052,8 +1129,9 @@ int v5_perm_launch(int nviews, const aggdev::f2* const* G, const aggdev::fg_t* c
 }
 
 int v5_wta_launch(int nviews, const float* const* q, int64_t* const* keys, int w, int h, int count, int slice0,
-                  hipStream_t st) {
+                  const unsigned* skip_if, hipStream_t st) {
     v5::Wta5Args wa;
+    wa.skip_if = skip_if;
     for (int v = 0; v < 2; ++v) { wa.q[v] = q[v < nviews ? v : 0]; wa.keys[v] = keys[v < nviews ? v : 0]; }
     const int K = v5::strips(w);
     const size_t np = (size_t)K * h * v5::OWS;
@@ -1083,6 +1161,9 @@ bool v5_supported(const smx_params* p) {
         return false;
     return true;
 }
+
+// materialised cost volumes: the cost parameters do not matter (the kernel checks the VALUES it loads), radius and eps do
+bool v5_supported_cost(const smx_params* p) { return p->radius == v5::R && p->eps >= 1.0 && p->eps < 1e30; }
 
 int v5_launch(const v5::Args& a, hipStream_t st) {
     int dev = 0, ncu = 256;

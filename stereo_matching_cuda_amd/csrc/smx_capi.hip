@@ -58,7 +58,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                  uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
                  hipStream_t st, const AggOpts& opt, AggInfo* info);
 size_t v5_fix_bytes(int w, int h, int nviews);
-int v4_read_status(const void* d_ws, unsigned* out);
+int v4_read_status(const void* d_ws, unsigned* out, int nwords);
 void v4_geometry(int* ow, int* bh);
 // smx_agg_v5.hip
 bool v5_supported(const smx_params* p);
@@ -267,11 +267,20 @@ int smx_agg_geometry(int radius, int* strip_cols, int* band_rows, int* tile_cols
 int smx_dev_agg_status(const void* d_workspace) {
     SMX_ARG(d_workspace);
     unsigned st = 0;
-    int rc = v4_read_status(d_workspace, &st);
+    int rc = v4_read_status(d_workspace, &st, 1);
     if (rc) return rc;
     if (st != 0)
         return fail(SMX_E_HIP, "fused aggregation: hand-off wait of work item %u timed out (results invalid)",
                     st - 1);
+    return SMX_OK;
+}
+
+int smx_dev_agg_fallback(const void* d_workspace, int* ring_walker_reran) {
+    SMX_ARG(d_workspace && ring_walker_reran);
+    unsigned st[2] = {0, 0};
+    int rc = v4_read_status(d_workspace, st, 2);
+    if (rc) return rc;
+    *ring_walker_reran = st[1] != 0;
     return SMX_OK;
 }
 

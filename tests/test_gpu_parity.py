@@ -416,6 +416,18 @@ def test_comb_walker_fuzz(orc, seed):
     r = _device_pair(Il, Ir, D, path=5, dminl=dminl, dminr=dminr, want_agg=False, params=p)     # the comb-ordered scratch + k_v5_wta
     for k in KEYS:
         _eq(r[k], want[k], f"seed {seed} w={w} h={h} D={D} scratch layout {k}")
+    # the reference's calling convention: materialised cost volumes through the same kernel (guidedFilter.cu:198)
+    import torch
+    from stereo_matching_cuda_amd.device import PairPipeline
+    wc = orc.stereo_pair(Il, Ir, D, dminl=dminl, dminr=dminr, want_cost=True, params=po)
+    pipe = PairPipeline(w, h, D, dminl=dminl, dminr=dminr, params=p)
+    pipe.aggregate(torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda(), torch.from_numpy(wc["costl"]).cuda(),
+                   torch.from_numpy(wc["costr"]).cuda())
+    assert smx.lib().smx_last_agg_path() == (5 if w * h >= 4 else 2)
+    pipe.finish()
+    r = pipe.results()
+    for k in KEYS:
+        _eq(r[k], want[k], f"seed {seed} w={w} h={h} D={D} cost volumes {k}")
 
 
 @pytest.mark.parametrize("radius,w,h", [(0, 128, 52), (0, 129, 53), (4, 64, 26), (4, 65, 78), (4, 192, 27), (4, 64, 16), (9, 130, 33), (1, 70, 48)])
@@ -444,13 +456,94 @@ def test_materialised_cost_volume_takes_the_fused_path(tsukuba_gray, tsukuba_ora
     dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
     cl = torch.from_numpy(tsukuba_oracle["costl"]).cuda()
     cr = torch.from_numpy(tsukuba_oracle["costr"]).cuda()
-    pipe = PairPipeline(384, 288, 16, dminl=-15, dminr=0, want_agg=True)
-    pipe.aggregate(dl, dr, cl, cr)
-    assert smx.lib().smx_last_agg_path() == 2
-    pipe.finish()
-    r = pipe.results()
-    for k in KEYS + ("aggl", "aggr"):
-        _eq(r[k], tsukuba_oracle[k], k)
+    for want_agg in (True, False):
+        pipe = PairPipeline(384, 288, 16, dminl=-15, dminr=0, want_agg=want_agg)
+        pipe.aggregate(dl, dr, cl, cr)
+        assert smx.lib().smx_last_agg_path() == 5, "radius 9: the comb walker, loading p instead of building it"
+        pipe.finish()
+        r = pipe.results()
+        assert not _fallback_ran(pipe), "costs from costVolume.cu:187 are +0 or normal: the queued ring walker must not run"
+        for k in KEYS + (("aggl", "aggr") if want_agg else ()):
+            _eq(r[k], tsukuba_oracle[k], k)
+    smx.lib().smx_set_agg_path(3)
+    try:
+        pipe = PairPipeline(384, 288, 16, dminl=-15, dminr=0, want_agg=True)
+        pipe.aggregate(dl, dr, cl, cr)
+        assert smx.lib().smx_last_agg_path() == 2
+        pipe.finish()
+        r = pipe.results()
+        for k in KEYS + ("aggl", "aggr"):
+            _eq(r[k], tsukuba_oracle[k], "ring walker " + k)
+    finally:
+        smx.lib().smx_set_agg_path(0)
+
+
+def _fallback_ran(pipe):
+    import ctypes as C
+    import torch
+    torch.cuda.synchronize()
+    f = C.c_int(-1)
+    smx.check(smx.lib().smx_dev_agg_fallback(C.c_void_p(pipe.ws.data_ptr()), C.byref(f)))
+    return bool(f.value)
+
+
+@pytest.mark.parametrize("w,h,D", _ragged_shapes(*_COMB, False))
+def test_cost_volume_convention_on_the_comb_walker(orc, w, h, D):
+    """guidedFilter.cu:198-200 (`copyFromBigToLittleOnGPU`: the slice loop reads a materialised volume) on the comb walker at
+    every strip / band boundary shape: quads that start at column -1 (strip 0), quads that run over the end of a row, of the
+    plane, of the volume (clamped and shifted back), bands below the image; both q layouts; one and several slices per launch."""
+    import torch
+    from stereo_matching_cuda_amd.device import PairPipeline
+    rng = np.random.default_rng(w * 11 + h * 5 + D)
+    base = rng.integers(0, 256, size=(h, w + D), dtype=np.uint8)
+    Il = np.ascontiguousarray(base[:, :w])
+    Ir = np.ascontiguousarray(base[:, D // 2: D // 2 + w])
+    want = orc.stereo_pair(Il, Ir, D, want_cost=True, want_agg=True)
+    dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
+    cl, cr = torch.from_numpy(want["costl"]).cuda(), torch.from_numpy(want["costr"]).cuda()
+    for want_agg, sif in ((True, None), (False, None), (False, 1)):
+        pipe = PairPipeline(w, h, D, want_agg=want_agg, slices_in_flight=sif)
+        pipe.aggregate(dl, dr, cl, cr)
+        # (a plane of fewer than four costs cannot hold a 16-byte quad: the ring walker takes those)
+        assert smx.lib().smx_last_agg_path() == (5 if w * h >= 4 else 2)
+        pipe.finish()
+        r = pipe.results()
+        assert not _fallback_ran(pipe)
+        for k in KEYS + (("aggl", "aggr") if want_agg else ()):
+            _eq(r[k], want[k], f"agg={want_agg} sif={sif} {k}")
+
+
+@pytest.mark.parametrize("kind", ["negative", "minus_zero", "denormal", "tiny", "huge", "inf", "nan"])
+def test_cost_values_outside_the_comb_walkers_argument_fall_back_on_the_device(orc, kind):
+    """The comb walker's exactness argument needs every cost to be +0 or a normal number in [2^-60, 2^60].  A volume with ONE
+    value outside that set (in an interior strip, at an image corner) must still give the oracle's result bit for bit: the
+    cost wave raises the second status word and the queued ring walker redoes the chunk -- no host round trip."""
+    import torch
+    from stereo_matching_cuda_amd.device import PairPipeline
+    rng = np.random.default_rng(77)
+    w, h, D = 330, 47, 3
+    I = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    cost = (rng.random((D, h, w), dtype=np.float32) * 2.5).astype(np.float32)
+    bad = {"negative": -0.75, "minus_zero": -0.0, "denormal": 1e-41, "tiny": 2.0 ** -70, "huge": 2.0 ** 70, "inf": np.inf,
+           "nan": np.nan}[kind]
+    for (z, y, x) in ((1, 20, 200), (D - 1, h - 1, w - 1), (0, 0, 0)):
+        c = cost.copy()
+        c[z, y, x] = np.float32(bad)
+        b1, d1, m1, a1 = orc.guided_filter(I, c, -2, want_agg=True)
+        b2, d2 = smx.init_wta(h, w)
+        m2, a2 = smx.compute_guided_filter(I, c, b2, d2, -2, want_agg=True)
+        assert smx.lib().smx_last_agg_path() == 5
+        _eq(m2, m1, f"{kind} at {(z, y, x)} mean")
+        _eq(a2, a1, f"{kind} at {(z, y, x)} agg")
+        _eq(b2, b1, f"{kind} at {(z, y, x)} best")
+        _eq(d2, d1, f"{kind} at {(z, y, x)} dmap")
+    # ... and the device-pointer call reports that the fall-back ran (and does not for the clean volume)
+    dI = torch.from_numpy(I).cuda()
+    for vol, expect in ((c, True), (cost, False)):
+        pipe = PairPipeline(w, h, D, dminl=-2, dminr=-2)
+        pipe.init_keys()
+        pipe.aggregate_view(0, dI, dI, torch.from_numpy(vol).cuda())
+        assert _fallback_ran(pipe) == expect, (kind, expect)
 
 
 def test_pair_step_is_capturable_in_a_hip_graph(tsukuba_gray, tsukuba_oracle):
