@@ -49,6 +49,11 @@ def main():
     ap.add_argument("--preheat-s", type=float, default=0.3, help="seconds of untimed steps in front of the warmup steps")
     ap.add_argument("--slices-in-flight", type=int, default=None,
                     help="upper bound on the slices of one walker launch (default: all local slices in one launch)")
+    ap.add_argument("--source", default="images", choices=["images", "cost"],
+                    help="images (the headline): the matching costs are built inside the aggregation kernel from the two images; "
+                         "cost: the reference's own data flow (main.cu:80-82 then :133-134, guidedFilter.cu:198-233) -- both raw "
+                         "cost volumes materialised in HBM before the timed region, every step reads p and writes / consumes q: "
+                         "the literal 8 B per cell of the roofline accounting.  Reported separately, never the headline")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend of the N > 1 exchange step: nccl = RCCL over xGMI, one GPU per rank (what the "
                          "scaling run uses); gloo = the SAME control flow with the keys staged through host memory, ranks may "
@@ -97,6 +102,11 @@ def main():
     pipe = sp.pipe
     local_slices = pipe.s_end - pipe.s_begin
 
+    cost_l = cost_r = None
+    if args.source == "cost":
+        cost_l, cost_r = pipe.cost_volumes(dl, dr)      # resident in HBM like the images; built once, outside every timed region
+        torch.cuda.synchronize(device)
+
     def step(events=None):
         if events is not None:
             es = torch.cuda.Event(enable_timing=True)
@@ -107,7 +117,10 @@ def main():
         pipe.init_keys()
         if events is not None:
             e0.record()
-        pipe.aggregate_pair(dl, dr)   # both views per kernel launch
+        if cost_l is None:
+            pipe.aggregate_pair(dl, dr)   # both views per kernel launch
+        else:
+            pipe.aggregate_pair_cost(dl, dr, cost_l, cost_r)
         if events is not None:
             e1.record()
         if world > 1:
@@ -204,7 +217,7 @@ def main():
     tname = {"kitti": "r05_traffic.json", "motorcycle": "r05_motorcycle_traffic.json",
              "4k": "r05_4k_traffic.json"}.get(args.workload) if args.mode == "exact" else None
     tpath = os.path.join(ROOT, "profiles", tname) if tname else None
-    if world == 1 and tpath and args.slices_in_flight is None and os.path.exists(tpath):
+    if world == 1 and tpath and args.slices_in_flight is None and args.source == "images" and os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             # the profile belongs to one build of the library: a stale file is not quoted
@@ -220,7 +233,9 @@ def main():
 
     result = {
         "metric": "disparity MPix/s (stereo pair -> L+R disparity + occlusion-filled map)"
-                  + ("" if args.mode == "exact" else " -- FAST mode, NOT bit-exact, not the headline"),
+                  + ("" if args.mode == "exact" else " -- FAST mode, NOT bit-exact, not the headline")
+                  + ("" if args.source == "images" else " -- from materialised cost volumes (read p + write q), not the headline"),
+        "source": args.source,
         "mode": args.mode,
         "value": (w * h * args.steps) / dt / 1e6,
         "unit": "MPix/s",

@@ -204,6 +204,14 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
                                int64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
                                size_t workspace_bytes, void* stream);
 
+/* The same with the two cost volumes materialised by the caller -- main.cu:80-82 followed by main.cu:133-134, i.e. the
+ * reference's own data flow: read the raw cost, write / consume the aggregated cost (guidedFilter.cu:198-233).  Slice s of a
+ * volume at d_cost_*[(s - s_begin) * w*h], as for smx_dev_aggregate_wta. */
+int smx_dev_aggregate_wta_pair_cost(const smx_params* p, const uint8_t* d_left, const uint8_t* d_right,
+                                    const float* d_cost_l, const float* d_cost_r, int w, int h, int dminl, int dminr,
+                                    int s_begin, int s_end, int64_t* d_keys, uint8_t* d_mean_u8, float* d_agg,
+                                    void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* Synchronous health check of the last smx_dev_aggregate_wta[_pair] call that used d_workspace:
  * copies the call's status word back (call it after synchronising the launch stream).  SMX_E_HIP if
  * a workgroup of the fused kernel gave up waiting for another one (its left neighbour strip or the

@@ -84,6 +84,7 @@ SIGNATURES = {
     "smx_agg_workspace_bytes_for": (_sz, [_PP, _i, _i, _i]),
     "smx_dev_aggregate_wta": (_i, [_PP, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "smx_dev_aggregate_wta_pair": (_i, [_PP, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "smx_dev_aggregate_wta_pair_cost": (_i, [_PP, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "smx_dev_agg_status": (_i, [_vp]),
     "smx_dev_agg_fallback": (_i, [_vp, C.POINTER(_i)]),
     "smx_dev_init_keys": (_i, [_vp, _i64, _vp]),

@@ -134,6 +134,9 @@ constexpr int WMAP = SMX_V5_WMAP;
 #ifndef SMX_V5_S2_KEEP
 #define SMX_V5_S2_KEEP 12
 #endif
+#ifndef SMX_V5_TOUCH
+#define SMX_V5_TOUCH 0      // (A/B: load-to-LDS touches of the next band's cost lines: slower, 0.84 against 0.78 ms per KITTI pair)
+#endif
 constexpr int S2_KEEP = SMX_V5_S2_KEEP;     // vector-memory operations a stage-2 wave issues behind its record store in an interior slot
 constexpr int PRIO_COST = SMX_V5_PRIO_COST, PRIO_S1 = SMX_V5_PRIO_S1, PRIO_S2HEAD = SMX_V5_PRIO_S2HEAD, PRIO_SCAN = SMX_V5_PRIO_SCAN;
 
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     __shared__ int s_item, s_next;
     __shared__ unsigned s_seen;                                     // last value read from the left neighbour's flag
     __shared__ unsigned s_peek[2];                                  // the flag as peeked at during slot sl -> [(sl + 1) & 1], read by every wave at the top of slot sl + 1
+    __shared__ unsigned touch_sink[64];                             // where the cost wave's prefetch touches of a cost volume land (never read)
     __shared__ unsigned s_x1;                                       // stage-2 waves that have taken their rows out of tile 2 (counts up through an item)
 
     const int lane = threadIdx.x & 63;
@@ -258,6 +262,11 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     constexpr int NQROW = SW / 4;                                   // quads per tile row (76 / 57)
     constexpr int NCT = 64;                                         // cost threads: the cost wave
     constexpr int NRB = 4;                                          // rounds whose loads are in flight together
+#ifndef SMX_V5_NRBC
+#define SMX_V5_NRBC 4
+#endif
+    constexpr int NRBC = SMX_V5_NRBC;                               // ... with materialised cost volumes (their quads come from HBM)
+    static_assert(2 * NRBC >= (BH * (SW / 4) + 63) / 64, "two batches");
     constexpr int NCT2 = 0;
     constexpr int NQT = BH * NQROW;                                 // quads per band
     constexpr int NRQ = (NQT - NCT2 + NCT - 1) / NCT;               // rounds
@@ -419,7 +428,8 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // (loading a band ahead of its slot -- 56 registers through the slot -- spills and is slower: measured)
         u4 cw_ra[CWN], cw_rb[CWN];
         auto cw_issue = [&](int ib, auto R0c, auto EDGEc, auto SRCc) {
-            constexpr int R0 = decltype(R0c)::value, R1 = R0 + NRB < CWN ? R0 + NRB : CWN;
+            constexpr int NB = decltype(SRCc)::value ? NRBC : NRB;   // (cost volumes: larger batches, see eval_band_p)
+            constexpr int R0 = decltype(R0c)::value, R1 = R0 + NB < CWN ? R0 + NB : CWN;
             constexpr bool EDGE = decltype(EDGEc)::value, SRCC = decltype(SRCc)::value;
             const unsigned bandb = (unsigned)(BH * ib) * fgw4, ymaxb = (unsigned)(h - 1) * fgw4;
             if (BH * ib + BH <= h) {
@@ -452,9 +462,29 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 }
             }
         };
+        // materialised cost volumes: the cost quads of a band come from HBM (the image planes from L2), and they are consumed in the
+        // slot they are issued in -- their latency sat on the cost wave's path twice per slot (0.78 ms per KITTI pair against 0.63
+        // from the images).  Holding a band of them in registers across the slot spills (28 more live registers: 0.96 ms).
+        // Instead the cost wave TOUCHES the next band's lines a slot ahead -- one dword per 128 bytes of its ten row segments,
+        // 70 lanes of two load-to-LDS instructions, no register, nothing waits for them -- so that the real loads hit in L2.
+        auto cw_touch_p = [&](int ib) {
+            if constexpr (ROLE == ROLE_COST) {
+                constexpr int SEGS = (SW * 4 + 124 + 127) / 128;            // 128-byte lines a row segment of SW costs can touch (7)
+                static_assert(BH * SEGS <= 128, "two touch instructions per band");
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int l = min(opaque(lane) + 64 * half, BH * SEGS - 1);
+                    const int row = l / SEGS, seg = l - row * SEGS;
+                    const int y = min(BH * ib + row, h - 1);
+                    const int off = min(max((y * w + base1) * 4 + seg * 128, 0), (int)plane4 - 4);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(r_c, (__attribute__((address_space(3))) void*)touch_sink, 4, off, 0, 0, 0);
+                }
+            }
+        };
         auto cw_finish = [&](int ib, float* dst, auto R0c, auto EDGEc, auto SRCc) {
             constexpr bool EDGE = decltype(EDGEc)::value, SRCC = decltype(SRCc)::value;
-            constexpr int R0 = decltype(R0c)::value, R1 = R0 + NRB < CWN ? R0 + NRB : CWN;
+            constexpr int NB = SRCC ? NRBC : NRB;
+            constexpr int R0 = decltype(R0c)::value, R1 = R0 + NB < CWN ? R0 + NB : CWN;
             const unsigned bandb = (unsigned)(BH * ib) * fgw4, ymaxb = (unsigned)(h - 1) * fgw4;
             char* const dstb = (char*)dst;
 #pragma unroll
@@ -508,18 +538,21 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         auto eval_band_p = [&](int ib, float* dst) {
             static_assert(2 * NRB >= CWN, "two batches");
             auto run = [&](auto EDGEc, auto SRCc) {
+                constexpr int NB = decltype(SRCc)::value ? NRBC : NRB;
                 cw_issue(ib, std::integral_constant<int, 0>{}, EDGEc, SRCc);
                 cw_finish(ib, dst, std::integral_constant<int, 0>{}, EDGEc, SRCc);
-                if constexpr (NRB < CWN) {
-                    cw_issue(ib, std::integral_constant<int, NRB>{}, EDGEc, SRCc);
-                    cw_finish(ib, dst, std::integral_constant<int, NRB>{}, EDGEc, SRCc);
+                if constexpr (NB < CWN) {
+                    cw_issue(ib, std::integral_constant<int, NB>{}, EDGEc, SRCc);
+                    cw_finish(ib, dst, std::integral_constant<int, NB>{}, EDGEc, SRCc);
                 }
             };
             // (versions of the whole band: the interior one has no trace of the edge handling, the cost-volume one none of the
             // cost evaluation)
             const bool edge = xedge || BH * ib + BH > h;
-            if (A.src_cost) { if (edge) run(std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{}); }
-            else if (edge) run(std::true_type{}, std::false_type{});
+            if (A.src_cost) {
+                if (SMX_V5_TOUCH) cw_touch_p(ib + 1);
+                if (edge) run(std::true_type{}, std::true_type{}); else run(std::false_type{}, std::true_type{});
+            } else if (edge) run(std::true_type{}, std::false_type{});
             else { V5_MARK("cost begin"); run(std::false_type{}, std::false_type{}); V5_MARK("cost end"); }
         };
         // guidance of the output rows of iteration ib: FEW, WIDE loads -- a vector-memory instruction costs its wave and the CU's
@@ -827,7 +860,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             g1_load(1, std::integral_constant<int, 1>{});
             if (pred) { cin1 = CI(-1); hand_in(false, hreg); }
         }
-        if constexpr (ROLE == ROLE_COST) eval_band_p(0, T1(0));
+        if constexpr (ROLE == ROLE_COST) {
+            eval_band_p(0, T1(0));
+        }
         auto slot = [&](auto PARc, int sl) {
             constexpr int PAR = decltype(PARc)::value;
             [[maybe_unused]] const int i = sl;          // (V5_STAMP)

@@ -433,13 +433,14 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
     return SMX_OK;
 }
 
-int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const uint8_t* d_right,
-                               int w, int h, int dminl, int dminr, int s_begin, int s_end,
-                               int64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
-                               size_t workspace_bytes, void* stream) {
+static int aggregate_pair(const char* who, const smx_params* p, const uint8_t* d_left, const uint8_t* d_right,
+                          const float* d_cost_l, const float* d_cost_r, int w, int h, int dminl, int dminr, int s_begin,
+                          int s_end, int64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
+                          size_t workspace_bytes, void* stream) {
     SMX_ARG(p && d_left && d_right && d_keys && d_workspace);
     SMX_ARG(w >= 2 && h >= 1 && s_begin >= 0 && s_end >= s_begin && p->radius >= 0);
-    { int rcd = check_same_device(d_workspace, "smx_dev_aggregate_wta_pair"); if (rcd) return rcd; }
+    SMX_ARG((d_cost_l != nullptr) == (d_cost_r != nullptr));
+    { int rcd = check_same_device(d_workspace, who); if (rcd) return rcd; }
     hipStream_t st = (hipStream_t)stream;
     stage_mark(ST_BEGIN, st);
     const int64_t n = (int64_t)w * h;
@@ -447,25 +448,42 @@ int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const
     if (v4_supported(p) && g_agg_path != 1) {
         const uint8_t* guide[2] = {d_left, d_right};
         const uint8_t* other[2] = {d_right, d_left};
+        const float* cost[2] = {d_cost_l, d_cost_r};
         const int dmin[2] = {dminl, dminr};
         int64_t* keys[2] = {d_keys, d_keys + n};
         uint8_t* mean[2] = {d_mean_u8, d_mean_u8 ? d_mean_u8 + n : nullptr};
         float* agg[2] = {d_agg, d_agg ? d_agg + vol : nullptr};
         g_launches = 0;
-        int rc2 = aggregate_fused(g_agg_path, p, 2, guide, other, nullptr, w, h, dmin, s_begin, s_end, keys,
+        int rc2 = aggregate_fused(g_agg_path, p, 2, guide, other, d_cost_l ? cost : nullptr, w, h, dmin, s_begin, s_end, keys,
                                d_mean_u8 ? mean : nullptr, d_agg ? agg : nullptr, d_workspace,
                                workspace_bytes, st, &g_launches);
         if (rc2) return rc2;
         return SMX_OK;
     }
-    if (g_agg_path >= 2)
-        return fail(SMX_E_ARG, "smx_dev_aggregate_wta_pair: fused path forced but radius > 9");
-    int rc = smx_dev_aggregate_wta(p, d_left, d_right, nullptr, w, h, dminl, s_begin, s_end, d_keys,
+    if (g_agg_path >= 2) return fail(SMX_E_ARG, "%s: fused path forced but radius > 9", who);
+    int rc = smx_dev_aggregate_wta(p, d_left, d_right, d_cost_l, w, h, dminl, s_begin, s_end, d_keys,
                                    d_mean_u8, d_agg, d_workspace, workspace_bytes, stream);
     if (rc) return rc;
-    return smx_dev_aggregate_wta(p, d_right, d_left, nullptr, w, h, dminr, s_begin, s_end, d_keys + n,
+    return smx_dev_aggregate_wta(p, d_right, d_left, d_cost_r, w, h, dminr, s_begin, s_end, d_keys + n,
                                  d_mean_u8 ? d_mean_u8 + n : nullptr, d_agg ? d_agg + vol : nullptr,
                                  d_workspace, workspace_bytes, stream);
+}
+
+int smx_dev_aggregate_wta_pair(const smx_params* p, const uint8_t* d_left, const uint8_t* d_right,
+                               int w, int h, int dminl, int dminr, int s_begin, int s_end,
+                               int64_t* d_keys, uint8_t* d_mean_u8, float* d_agg, void* d_workspace,
+                               size_t workspace_bytes, void* stream) {
+    return aggregate_pair("smx_dev_aggregate_wta_pair", p, d_left, d_right, nullptr, nullptr, w, h, dminl, dminr, s_begin, s_end,
+                          d_keys, d_mean_u8, d_agg, d_workspace, workspace_bytes, stream);
+}
+
+int smx_dev_aggregate_wta_pair_cost(const smx_params* p, const uint8_t* d_left, const uint8_t* d_right,
+                                    const float* d_cost_l, const float* d_cost_r, int w, int h, int dminl, int dminr,
+                                    int s_begin, int s_end, int64_t* d_keys, uint8_t* d_mean_u8, float* d_agg,
+                                    void* d_workspace, size_t workspace_bytes, void* stream) {
+    SMX_ARG(d_cost_l && d_cost_r);
+    return aggregate_pair("smx_dev_aggregate_wta_pair_cost", p, d_left, d_right, d_cost_l, d_cost_r, w, h, dminl, dminr, s_begin,
+                          s_end, d_keys, d_mean_u8, d_agg, d_workspace, workspace_bytes, stream);
 }
 
 /* ------------------------------------------------------------------------------------------

@@ -71,9 +71,37 @@ class PairPipeline:
         self.init_keys()
         if cost_l is None and cost_r is None:
             self.aggregate_pair(gray_l, gray_r)
+        elif cost_l is not None and cost_r is not None:
+            self.aggregate_pair_cost(gray_l, gray_r, cost_l, cost_r)
         else:
             self.aggregate_view(0, gray_l, gray_r, cost_l)
             self.aggregate_view(1, gray_r, gray_l, cost_r)
+
+    def aggregate_pair_cost(self, gray_l, gray_r, cost_l, cost_r):
+        """Both views per launch from materialised cost volumes of this rank's slices (smx_dev_aggregate_wta_pair_cost):
+        the reference's data flow, read p + write q."""
+        with self._on_device():
+            L, P, st = self.lib, C.byref(self.params), self._stream()
+            _lib.check(L.smx_set_max_slices_per_launch(self.slices_in_flight))
+            try:
+                _lib.check(L.smx_dev_aggregate_wta_pair_cost(
+                    P, _dp(gray_l), _dp(gray_r), _dp(cost_l), _dp(cost_r), self.w, self.h, self.dminl, self.dminr,
+                    self.s_begin, self.s_end, _dp(self.keys), _dp(self.mean), _dp(self.agg), _dp(self.ws), self.ws_bytes, st))
+            finally:
+                L.smx_set_max_slices_per_launch(0)
+
+    def cost_volumes(self, gray_l, gray_r):
+        """The two raw cost volumes of this rank's slices, resident in HBM (smx_dev_cost_volume; main.cu:80-82)."""
+        n = self.s_end - self.s_begin
+        cl = torch.empty((n, self.h, self.w), dtype=torch.float32, device=self.device)
+        cr = torch.empty_like(cl)
+        with self._on_device():
+            L, P, st = self.lib, C.byref(self.params), self._stream()
+            _lib.check(L.smx_dev_cost_volume(P, _dp(gray_l), _dp(gray_r), _dp(cl), self.w, self.w, self.h, self.dminl,
+                                             self.s_begin, self.s_end, st))
+            _lib.check(L.smx_dev_cost_volume(P, _dp(gray_r), _dp(gray_l), _dp(cr), self.w, self.w, self.h, self.dminr,
+                                             self.s_begin, self.s_end, st))
+        return cl, cr
 
     def aggregate_pair(self, gray_l, gray_r):
         """Both views per kernel launch (smx_dev_aggregate_wta_pair)."""

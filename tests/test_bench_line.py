@@ -46,6 +46,17 @@ def test_slices_in_flight_is_what_ran():
     assert r["config"]["slices_in_flight"] == 5 and r["config"]["walker_launches_per_call"] == 4
 
 
+def test_cost_volume_source_line():
+    """`--source cost`: the reference's data flow -- the raw volumes resident in HBM, the comb walker reads p and writes q."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tsukuba", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--preheat-s", "0", "--source", "cost"], capture_output=True, text=True, timeout=600,
+                       cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = _last_json_line(p.stdout)
+    assert r["source"] == "cost" and "not the headline" in r["metric"] and r["value"] > 0
+    assert r["config"]["walker_launches_per_call"] == 1 and 0 < r["roofline"]["frac"] < 1
+
+
 def test_two_ranks_launch_line_on_one_gpu():
     """The driver's N > 1 launch line (torch.distributed.run, one process per rank) with two ranks sharing cuda:0."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")

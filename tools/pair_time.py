@@ -20,8 +20,12 @@ sif = int(os.environ["SMX_SIF"]) if "SMX_SIF" in os.environ else None       # sl
 pipe = PairPipeline(w, h, D, slices_in_flight=sif)
 dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
 smx.check(smx.lib().smx_set_agg_path(path))
+cost = pipe.cost_volumes(dl, dr) if os.environ.get("SMX_SRC", "") == "cost" else None     # materialised cost volumes (A/B runs)
 def step():
-    pipe.init_keys(); pipe.aggregate_pair(dl, dr); pipe.finish()
+    pipe.init_keys()
+    if cost is None: pipe.aggregate_pair(dl, dr)
+    else: pipe.aggregate_pair_cost(dl, dr, cost[0], cost[1])
+    pipe.finish()
 for _ in range(N): step()
 torch.cuda.synchronize()
 out = []
