@@ -114,13 +114,10 @@ def main():
             e1 = torch.cuda.Event(enable_timing=True)
             ee = torch.cuda.Event(enable_timing=True)
             es.record()
-        pipe.init_keys()
         if events is not None:
             e0.record()
-        if cost_l is None:
-            pipe.aggregate_pair(dl, dr)   # both views per kernel launch
-        else:
-            pipe.aggregate_pair_cost(dl, dr, cost_l, cost_r)
+        # both views per kernel launch; the call presets the WTA keys itself (smx_set_keys_fresh: no smx_dev_init_keys launch)
+        pipe.aggregate(dl, dr, cost_l, cost_r)
         if events is not None:
             e1.record()
         if world > 1:

@@ -248,6 +248,11 @@ int smx_last_agg_path(void);
  * smx_last_agg_chunk reports what the calling thread's last fused aggregation did: slices per walker launch (of the first,
  * i.e. largest, launch) and the number of walker launches. */
 int smx_set_max_slices_per_launch(int n);
+/* d_keys of smx_dev_aggregate_wta[_pair[_cost]] is IN/OUT (shards and chunks accumulate into it; initialise with
+ * smx_dev_init_keys).  smx_set_keys_fresh(1) tells the calling thread's following aggregation calls that the keys hold
+ * nothing yet: the call's first WTA pass starts from the identity instead of loading them, which saves the
+ * smx_dev_init_keys launch (7 us and 7.5 MB of stores per KITTI pair).  smx_set_keys_fresh(0) restores IN/OUT. */
+int smx_set_keys_fresh(int on);
 int smx_last_agg_chunk(int* slices_per_launch, int* walker_launches);
 /* Tile geometry of the fused aggregation for a box radius: output columns per strip, rows per band,
  * columns computed per strip (strip_cols + 2*radius + 1).  For tests that aim at tile boundaries. */

@@ -98,6 +98,7 @@ SIGNATURES = {
     "smx_set_agg_path": (_i, [_i]),
     "smx_last_agg_path": (_i, []),
     "smx_set_max_slices_per_launch": (_i, [_i]),
+    "smx_set_keys_fresh": (_i, [_i]),
     "smx_last_agg_chunk": (_i, [C.POINTER(_i), C.POINTER(_i)]),
     "smx_agg_geometry": (_i, [_i, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "smx_set_timing": (_i, [_i]),

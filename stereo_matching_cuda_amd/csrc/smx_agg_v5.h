@@ -70,6 +70,6 @@ int v5_perm_launch(int nviews, const aggdev::f2* const* G, const aggdev::fg_t* c
 // packed-key WTA over `count` comb-ordered q planes (slice slice0 ..) of `nviews` views -> keys [h][w]
 // (skip_if != NULL: a device word; the pass does nothing when it is nonzero)
 int v5_wta_launch(int nviews, const float* const* q, int64_t* const* keys, int w, int h, int count, int slice0,
-                  const unsigned* skip_if, hipStream_t st);
+                  const unsigned* skip_if, bool fresh, hipStream_t st);
 
 }  // namespace smx

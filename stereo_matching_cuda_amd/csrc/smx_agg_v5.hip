@@ -1093,6 +1093,7 @@ struct Wta5Args {
     const float* q[2];
     int64_t* keys[2];
     const unsigned* skip_if;      // != NULL: the pass does nothing if this word is nonzero (the comb walker's planes do not count)
+    int fresh;                    // != 0: the keys hold nothing yet (no smx_dev_init_keys ran): start from the identity, do not load them
 };
 // Four elements per lane, 16-byte loads: a strip row is OWS = 152 floats, so a plane is a whole number of quads, and the
 // planes are carved 256-byte aligned (aggregate_v4)
@@ -1115,7 +1116,7 @@ __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K
         const int rho = p / (L - 1), i1 = p - (L - 1) * rho;
         const int x = OWS * k + (k + 1 < K ? HW * i1 + rho : p);        // (the last strip is in column order)
         kp[j] = e < np && x < w ? keys + (size_t)y * w + x : nullptr;
-        key[j] = kp[j] ? *kp[j] : KEY_IDENTITY;
+        key[j] = kp[j] && !wa.fresh ? *kp[j] : KEY_IDENTITY;
     }
     // nothing of this lane lies in the image (the tail of a row of the last strip): no load at all
     bool any = false;
@@ -1164,9 +1165,10 @@ int v5_perm_launch(int nviews, const aggdev::f2* const* G, const aggdev::fg_t* c
 }
 
 int v5_wta_launch(int nviews, const float* const* q, int64_t* const* keys, int w, int h, int count, int slice0,
-                  const unsigned* skip_if, hipStream_t st) {
+                  const unsigned* skip_if, bool fresh, hipStream_t st) {
     v5::Wta5Args wa;
     wa.skip_if = skip_if;
+    wa.fresh = fresh ? 1 : 0;
     for (int v = 0; v < 2; ++v) { wa.q[v] = q[v < nviews ? v : 0]; wa.keys[v] = keys[v < nviews ? v : 0]; }
     const int K = v5::strips(w);
     const size_t np = (size_t)K * h * v5::OWS;

@@ -47,6 +47,7 @@ static thread_local StageTimer g_timer;
 static thread_local int g_agg_path = SMX_DEFAULT_AGG_PATH;
 static thread_local int g_last_path = 0;
 static thread_local int g_max_chunk = 0;     // smx_set_max_slices_per_launch
+static thread_local int g_keys_fresh = 0;    // smx_set_keys_fresh
 static thread_local AggInfo g_last_info;     // smx_last_agg_chunk
 
 // smx_agg_v4.hip (host orchestration of both fused walkers)
@@ -70,7 +71,12 @@ static int aggregate_fused(int path, const smx_params* p, int nviews, const uint
                            const int* dmin, int s_begin, int s_end, int64_t* const* d_keys,
                            uint8_t* const* d_mean_u8, float* const* d_agg, void* d_ws, size_t ws_bytes,
                            hipStream_t st, int* launches) {
+    if (g_keys_fresh && s_end <= s_begin) {
+        // nothing to aggregate: the promise "the call presets the keys" still holds
+        for (int v = 0; v < nviews; ++v) { int rk = launch_init_keys(d_keys[v], (int64_t)w * h, st); if (rk) return rk; }
+    }
     AggOpts opt;
+    opt.keys_fresh = g_keys_fresh != 0;
     opt.fast = path == 4;
     opt.walker = path == 3 ? 4 : path == 5 ? 5 : 0;
     opt.max_chunk = g_max_chunk;
@@ -232,6 +238,11 @@ int smx_set_agg_path(int path) {
 
 int smx_last_agg_path(void) { return g_last_path; }
 
+int smx_set_keys_fresh(int on) {
+    g_keys_fresh = on ? 1 : 0;
+    return SMX_OK;
+}
+
 int smx_set_max_slices_per_launch(int n) {
     if (n < 0) return fail(SMX_E_ARG, "smx_set_max_slices_per_launch: n must be >= 0 (0 = as many as the workspace holds)");
     g_max_chunk = n;
@@ -371,6 +382,7 @@ int smx_dev_aggregate_wta(const smx_params* p, const uint8_t* d_guide, const uin
         return SMX_OK;
     }
     g_last_path = 1;
+    if (g_keys_fresh) { int rk = launch_init_keys(d_keys, (int64_t)w * h, st); if (rk) return rk; }
     const size_t pb = plane_bytes(w, h);
     const int64_t n = (int64_t)w * h;
     char* base = (char*)align_up((size_t)d_workspace, WS_ALIGN);

@@ -82,6 +82,7 @@ struct AggOpts {
     bool fast = false;       // FAST mode (not bit-exact)
     int walker = 0;          // 0 choose, 4 ring walker forced, 5 comb walker forced (an error where it does not apply)
     int max_chunk = 0;       // upper bound on the slices of one walker launch; 0 = as many as the workspace holds
+    bool keys_fresh = false; // the keys hold nothing yet: the first WTA pass starts from the identity (no smx_dev_init_keys needed)
 };
 struct AggInfo {
     int walker_used = 0;     // 4 ring walker, 5 comb walker

@@ -68,14 +68,18 @@ class PairPipeline:
     def aggregate(self, gray_l, gray_r, cost_l=None, cost_r=None):
         """Cost build (fused unless cost_* given) + guided-filter aggregation + running WTA of this
         rank's slices, both views.  Leaves packed keys in self.keys."""
-        self.init_keys()
-        if cost_l is None and cost_r is None:
-            self.aggregate_pair(gray_l, gray_r)
-        elif cost_l is not None and cost_r is not None:
-            self.aggregate_pair_cost(gray_l, gray_r, cost_l, cost_r)
-        else:
-            self.aggregate_view(0, gray_l, gray_r, cost_l)
-            self.aggregate_view(1, gray_r, gray_l, cost_r)
+        # (no smx_dev_init_keys launch: the aggregation presets the keys itself, smx_set_keys_fresh)
+        self.lib.smx_set_keys_fresh(1)
+        try:
+            if cost_l is None and cost_r is None:
+                self.aggregate_pair(gray_l, gray_r)
+            elif cost_l is not None and cost_r is not None:
+                self.aggregate_pair_cost(gray_l, gray_r, cost_l, cost_r)
+            else:
+                self.aggregate_view(0, gray_l, gray_r, cost_l)
+                self.aggregate_view(1, gray_r, gray_l, cost_r)
+        finally:
+            self.lib.smx_set_keys_fresh(0)
 
     def aggregate_pair_cost(self, gray_l, gray_r, cost_l, cost_r):
         """Both views per launch from materialised cost volumes of this rank's slices (smx_dev_aggregate_wta_pair_cost):

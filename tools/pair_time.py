@@ -22,9 +22,8 @@ dl, dr = torch.from_numpy(Il).cuda(), torch.from_numpy(Ir).cuda()
 smx.check(smx.lib().smx_set_agg_path(path))
 cost = pipe.cost_volumes(dl, dr) if os.environ.get("SMX_SRC", "") == "cost" else None     # materialised cost volumes (A/B runs)
 def step():
-    pipe.init_keys()
-    if cost is None: pipe.aggregate_pair(dl, dr)
-    else: pipe.aggregate_pair_cost(dl, dr, cost[0], cost[1])
+    if cost is None: pipe.aggregate(dl, dr)
+    else: pipe.aggregate(dl, dr, cost[0], cost[1])
     pipe.finish()
 for _ in range(N): step()
 torch.cuda.synchronize()
