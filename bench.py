@@ -228,6 +228,20 @@ def main():
         except (ValueError, KeyError):
             traffic = None
 
+    # VALU issue capacity the walker launch used: its dynamic instruction count (committed PMC profile of this build and
+    # workload) x the SIMD cycles of its instruction mix / (LIVE launch duration x clock x SIMDs)  -- tools/valu.py
+    valu_frac = None
+    vpath = os.path.join(ROOT, "profiles", "r05_valu.json")
+    if world == 1 and args.workload == "kitti" and args.mode == "exact" and args.source == "images" and walk_avg_s > 0 \
+            and os.path.exists(vpath):
+        try:
+            vj = json.load(open(vpath))
+            if vj.get("library") == smx.lib().smx_version().decode():
+                valu_frac = (float(vj["walker_valu_instructions_per_launch"]) * float(vj["simd_cycles_per_valu_instruction"])
+                             / (walk_avg_s * float(vj["shader_clock_ghz"]) * 1e9 * float(vj["simds"])))
+        except (ValueError, KeyError):
+            valu_frac = None
+
     result = {
         "metric": "disparity MPix/s (stereo pair -> L+R disparity + occlusion-filled map)"
                   + ("" if args.mode == "exact" else " -- FAST mode, NOT bit-exact, not the headline")
@@ -268,6 +282,9 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
+            # which wall the kernel is nearer to: share of the chip's VALU issue capacity the launch used (null where no PMC
+            # profile of this build and workload is committed).  The kernel is bound by neither: dependent chains per wave.
+            "valu_frac": valu_frac,
             "traffic": traffic,
             "traffic_source": traffic_src,
             "avg_launch_ms": walk_avg_s * 1e3,

@@ -10,5 +10,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 500 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -- python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc_$C.log 2>&1
 done
 head -5 $O/kt/*/*kernel_stats.csv | cut -c1-150
-python3 $R/tools/traffic.py $O 2>&1 | tail -6
+python3 $R/tools/traffic.py $O $O/traffic.json 2>&1 | tail -6
 cut -c1-400 $O/bench.json

@@ -17,5 +17,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -- python3 $R/bench.py --no-cpu-baseline --steps 5 > $O/pmc_$C.log 2>&1
 done
 cat $O/kt/*/*kernel_stats.csv | cut -c1-150
-python3 $R/tools/traffic.py $O 2>&1 | tail -12
+python3 $R/tools/traffic.py $O $O/traffic.json 2>&1 | tail -12
 cut -c1-900 $O/bench.json

@@ -25,6 +25,23 @@ REGIONS = [  # name, waves of the role per workgroup, what
 CELLS = 10 * 152
 
 
+# SIMD cycles a wave64 VALU instruction occupies at four waves per SIMD, measured over whole launches with
+# tools/ubench/simd_rate.hip (profiles/r05_simd_rate.txt): plain f32 VOP2 / VOP3 (add, mul, fma) 3.0 (2.6 at eight waves);
+# everything packed, DPP, mixed-precision, packed-half or with source modifiers 4.3-4.8.  A v_pk_*_f32 is ONE pass of the
+# pipeline, not two (round 4 assumed two from the single-wave issue rate).
+def simd_cycles(ins):
+    op = ins.split()[0]
+    if not op.startswith("v_") or op.startswith(("v_readlane", "v_writelane", "v_readfirstlane")):
+        return 0.0
+    if op.startswith("v_pk_") and op.endswith("_f32"):
+        return 4.7
+    if "_dpp" in op or " row_shr" in ins or "wave_shr" in ins:
+        return 4.4
+    if "mix" in op or op.endswith("_f16") or "|" in ins or "sdwa" in op:
+        return 4.4
+    return 3.0
+
+
 def classify(ins):
     op = ins.split()[0]
     if op.startswith("s_nop"): return "s_nop"
@@ -32,7 +49,7 @@ def classify(ins):
     if op.startswith("ds_"): return "lds"
     if op.startswith(("buffer_", "global_", "scratch_")): return "vmem"
     if op.startswith("s_"): return "salu"
-    if op.startswith("v_pk_") and op.endswith("_f32"): return "valu_pk"      # two passes; the packed-half ops take one
+    if op.startswith("v_pk_") and op.endswith("_f32"): return "valu_pk"
     if "_dpp" in op or " row_shr" in ins or "wave_shr" in ins: return "valu_dpp"
     if op.startswith(("v_readlane", "v_writelane", "v_readfirstlane")): return "valu_lane"
     if op.startswith("v_"): return "valu"
@@ -51,9 +68,10 @@ def main(dst=None):
     out = []
     cols = ["valu", "valu_pk", "valu_dpp", "valu_lane", "salu", "s_nop", "s_waitcnt", "lds", "vmem"]
     out.append("k_v5_walk, interior path, instructions one wave executes per band (10 rows x 152 output columns = 1520 cells)")
-    out.append("(v_pk_*_f32 takes two passes of the 16-lane SIMD; `passes` = valu + 2 valu_pk + valu_dpp + valu_lane)")
+    out.append("(`cycles` = SIMD cycles of the region's VALU instructions at the measured per-class rates: plain f32 3.0, packed f32 4.7,")
+    out.append(" DPP / mixed / packed-half / modifiers 4.4 -- profiles/r05_simd_rate.txt; `cyc/64c` = the same per 64 cells)")
     out.append("")
-    out.append(f"{'region':10s} {'waves':>5s} " + " ".join(f"{c:>9s}" for c in cols) + f" {'passes':>7s} {'VALU/64c':>9s} {'SALU/64c':>9s}")
+    out.append(f"{'region':10s} {'waves':>5s} " + " ".join(f"{c:>9s}" for c in cols) + f" {'cycles':>7s} {'VALU/64c':>9s} {'SALU/64c':>9s} {'cyc/64c':>8s}")
     tot_v = tot_s = tot_p = 0.0
     for name, waves, what in REGIONS:
         try:
@@ -77,18 +95,20 @@ def main(dst=None):
                 blocks.append(cur); cur = []
         blocks.append(cur)
         cnt = collections.Counter()
+        cyc = 0.0
         for blk in blocks:
             if any(t.startswith(("v_div_scale", "v_div_fixup")) for t in blk):
                 continue
             for t in blk:
                 cnt[classify(t)] += 1
+                cyc += simd_cycles(t)
         valu = cnt["valu"] + cnt["valu_pk"] + cnt["valu_dpp"] + cnt["valu_lane"]
-        passes = valu + cnt["valu_pk"]
+        passes = cyc
         v64 = valu * waves / CELLS * 64
         s64 = (cnt["salu"] + cnt["s_nop"] + cnt["s_waitcnt"]) * waves / CELLS * 64
         tot_v += v64; tot_s += s64; tot_p += passes * waves / CELLS * 64
-        out.append(f"{name:10s} {waves:5d} " + " ".join(f"{cnt[c]:9d}" for c in cols) + f" {passes:7d} {v64:9.1f} {s64:9.1f}")
-    out.append(f"{'sum':10s} {'':5s} " + " ".join(f"{'':9s}" for _ in cols) + f" {'':7s} {tot_v:9.1f} {tot_s:9.1f}   (passes per 64 cells: {tot_p:.1f})")
+        out.append(f"{name:10s} {waves:5d} " + " ".join(f"{cnt[c]:9d}" for c in cols) + f" {passes:7.0f} {v64:9.1f} {s64:9.1f} {passes * waves / CELLS * 64:8.1f}")
+    out.append(f"{'sum':10s} {'':5s} " + " ".join(f"{'':9s}" for _ in cols) + f" {'':7s} {tot_v:9.1f} {tot_s:9.1f}   (SIMD cycles per 64 cells: {tot_p:.1f}; a CU has 4 SIMD-cycles per cycle)")
     out.append("")
     for name, waves, what in REGIONS:
         out.append(f"  {name:9s} {what}")
@@ -100,7 +120,8 @@ def main(dst=None):
     out.append("  cost: 7 per cell, 172 columns evaluated per 152 outputs                                         =  7.9 per 64 cells")
     out.append("  row scans: 4 columns x 43 groups per band, 40 (row, component) lanes of 64 at a time            =  7.2 per 64 cells")
     out.append("  floor                                                                                            = 49.2 per 64 cells")
-    out.append("Dynamic count of the whole kernel (profiles/r04_pmc_summary.txt, SQ_INSTS_VALU / cells x 64) is quoted in DESIGN.md.")
+    out.append(f"SIMD cycles per VALU instruction on this path: {tot_p / tot_v:.2f} (used by bench.py for roofline.valu_frac together with the")
+    out.append("dynamic SQ_INSTS_VALU of the whole kernel, profiles/r05_pmc_summary.txt)")
     txt = "\n".join(out)
     print(txt)
     if dst:
