@@ -41,6 +41,7 @@ struct Args {
     size_t q_plane;       // floats per slice of q
     int d0[2];            // disparity of local slice 0 per view
     int w, h, K, NI, nslices, nsv, nitems;
+    int P;                // slots between the starts of two items of a workgroup (period(h): items are pipelined, smx_agg_v5.hip)
     float* hand;          // hand-off records [parity][sv][iteration][REC_U x 4 floats]
     unsigned* flags;      // [sv][K]  published-record counters (zeroed before every launch)
     unsigned* ticket;     // work-item counter              (zeroed before every launch)
@@ -54,6 +55,16 @@ struct Args {
 inline int strips(int w) { return (w + OWS - 1) / OWS; }
 inline int bands(int h) { return (h + 2 * 9 + BH - 1) / BH + 2; }     // the q rows of iteration i end at 10 i - 28
 inline int records(int h) { return bands(h) + 2; }                   // hand-off records per (strip boundary, slice-view)
+// An item occupies its roles for fewer slots than it has: the cost wave for local slots -2 .. s1_last - 2, stage 1 for
+// -2 .. s1_last (s1_last = the slot of the last a/b row inside the image), stage 2 for 1 .. q_last (the last q row).  A
+// workgroup starts its next item after period(h) slots: the longest of those ranges (bands(h) - 1 or bands(h)), at least 4,
+// rounded up to an even number.
+inline int period(int h) {
+    const int s1_last = (h + 8) / 10, q_last = (h + 37) / 10;
+    int p = s1_last + 3 > q_last ? s1_last + 3 : q_last;
+    p = p < 4 ? 4 : p;
+    return p + (p & 1);     // even: the local slot of an item then has the parity of the workgroup's global slot (static ring slots)
+}
 inline size_t sv_hand_floats(int h) { return (size_t)2 * records(h) * REC_U * 4; }   // parity x records
 
 }  // namespace v5

@@ -31,6 +31,8 @@
 // Hand-off, tickets and the bounded flag waits are those of smx_agg_v4.hip (strip-major tickets: the left neighbour of
 // an item always holds an earlier ticket); every wave takes the flag value it acts on from an LDS word written in the
 // slot before (s_peek), so that all eight waves agree on whether the slot has the extra barrier of a wait.
+// Round 5: a workgroup's items are PIPELINED -- the front roles (cost wave, stage-1 scan lanes, stage 1) start the next
+// ticket every P = period(h) slots while stage 2 finishes the last three slots of the item before (see the slot loop).
 //
 // Exactness (all checked bit for bit by the CPU model tools/v5_model.cpp against the oracle): virtual rows and
 // columns outside the image hold -0, the exact additive identity, so the clamped window corners of
@@ -86,11 +88,16 @@ static_assert(REC_U == NHU + NCU, "record layout");
 #ifdef SMX_V5_STAMPS
 constexpr int STAMP_W = 12;     // 0..5: slot phases; 6..10: after each of the five row pairs (comb waves) / quarters of the scan / cost batches
 constexpr int STAMP_SLOTS = STAMP_W * 48;
+// (the stamps are those of ONE workgroup -- SMX_V5_STAMPS mod 512 -- over 48 global slots from STAMP_G0: its items overlap)
+#ifndef SMX_V5_STAMP_G0
+#define SMX_V5_STAMP_G0 30
+#endif
+constexpr int STAMP_G0 = SMX_V5_STAMP_G0;
 __device__ unsigned long long g_stamps[10 * STAMP_SLOTS];
 #define V5_STAMP(n)                                                                          \
     do {                                                                                     \
-        if (item == SMX_V5_STAMPS && lane == 0 && i * STAMP_W + (n) < STAMP_SLOTS)            \
-            g_stamps[wave * STAMP_SLOTS + i * STAMP_W + (n)] = __builtin_amdgcn_s_memtime();  \
+        if ((int)blockIdx.x == SMX_V5_STAMPS % 512 && lane == 0 && i >= STAMP_G0 && (i - STAMP_G0) * STAMP_W + (n) < STAMP_SLOTS) \
+            g_stamps[wave * STAMP_SLOTS + (i - STAMP_G0) * STAMP_W + (n)] = __builtin_amdgcn_s_memtime();  \
     } while (0)
 #else
 #define V5_STAMP(n) ((void)0)
@@ -226,7 +233,8 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     __shared__ __attribute__((aligned(16))) float tile2s[NT2][TILE_F];
     __shared__ float cin1s[2][BH][2];                               // stage-1 row carries of the band the next scan pass takes (by pass parity)
     __shared__ float rcp_s[RCP_N];                                  // RN(1/area)
-    __shared__ int s_item, s_next;
+    __shared__ int s_queue[4];                                      // tickets of the workgroup's items, by item number & 3 (written by the cost wave a few slots ahead)
+    __shared__ unsigned s_peekn;                                    // the NEXT item's predecessor flag as peeked at in the last slot of the front item
     __shared__ unsigned s_seen;                                     // last value read from the left neighbour's flag
     __shared__ unsigned s_peek[2];                                  // the flag as peeked at during slot sl -> [(sl + 1) & 1], read by every wave at the top of slot sl + 1
     __shared__ unsigned touch_sink[64];                             // where the cost wave's prefetch touches of a cost volume land (never read)
@@ -271,55 +279,82 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     constexpr int NQT = BH * NQROW;                                 // quads per band
     constexpr int NRQ = (NQT - NCT2 + NCT - 1) / NCT;               // rounds
 
-    if (tid == 0) s_item = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (;;) {
-        wg_barrier();
-        const int item = s_item;
-        if (item >= A.nitems) break;
-        const int k = item / nsv;
-        const int sv = item - k * nsv;
-        const int view = sv / A.nslices;
-        const int slice = sv - view * A.nslices;
-        const int base1 = OWS * k - 1;          // image column of tile-1 column 0
-        const int base2 = OWS * k - R - 1;      // image column of tile-2 column 0 (= a/b column of the same comb lane)
-        const bool pred = k > 0 && !(WHATIF & (64 | 4096)), succ = k + 1 < K && !(WHATIF & (64 | 2048));
-        const int d = A.d0[view] + slice;
-        unsigned* const myflag = A.flags + (size_t)sv * K + k;
-        // Buffer descriptors: ONE over the fixed part of the workspace (both image planes, the guidance plane: the
-        // plane is chosen by a scalar offset), one over the hand-off records, one over this slice's q plane.
-        const unsigned fgw4 = ((unsigned)w + 2u * PADX) * 4u, w4 = (unsigned)w * 4u;
-        const rsrc_t r_fix = mk_rsrc(A.fix, A.fix_bytes);
-        const int o_fg1 = (int)A.o_fg[view], o_fg2 = (int)A.o_fg[view ^ 1];
-        // this strip's rows of the comb-ordered guidance planes
-        // (band-major: 5 NI row pairs of 16 B per lane for stage 1; per band 16 B + 4 B per lane for stage 2 -- smx_agg_v5.h)
-        const int o_g1p = (int)(A.o_g1p[view] + (unsigned)k * (unsigned)(5 * NI) * (CLP * 16u)),
-                  o_i2p = (int)(A.o_i2p[view] + (unsigned)k * (unsigned)NI * (CLP * 16u)),
-                  o_i2b = (int)(A.o_i2p[view] + (unsigned)K * (unsigned)NI * (CLP * 16u) + (unsigned)k * (unsigned)NI * (CLP * 4u));
-        const unsigned recb = (unsigned)(NI + 2) * REC_U * 16u;  // bytes per (parity, slice-view)  (smx_agg_v5.h records())
-        const rsrc_t r_hand = mk_rsrc(A.hand, (size_t)2 * nsv * recb);
-        const int o_in = (int)((((unsigned)(k - 1) & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
-        const int o_out = (int)((((unsigned)k & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
-        const rsrc_t r_q = mk_rsrc(A.q[view] + (size_t)slice * A.q_plane, A.q_plane * 4);
-        // q rows: comb-ordered scratch (row y of this strip at (k h + y) * OWS) or the caller's [h][w]
-        const int q_pitch = A.qperm ? OWS * 4 : (int)w4, q_row0 = A.qperm ? k * h * (OWS * 4) : 0;
-
-        // the strip has columns outside the image (virtual: -0)
-        const bool xedge = base1 < 0 || base1 + SW > w;
+    // ---- items pipelined across the workgroup's tickets (round 5) ---------------------------------------------------------
+    // An item needs the cost wave in its local slots -2 .. s1_last - 2, stage 1 in -2 .. s1_last, stage 2 in 1 .. q_last: every
+    // role idles for several of an item's NI + 2 slots.  The workgroup therefore starts a new item every P = A.P slots
+    // (max(s1_last + 3, q_last): NI - 1 or NI): the FRONT roles (cost wave, stage-1 scan lanes, stage 1) take the next ticket
+    // while stage 2 (and, in the first overlap slot, the stage-2 scan lanes) finish the last q_last - P + 3 slots of the BACK
+    // item.  One global slot counter g per wave; the front item's local slot is slf = g - P n - 2.  Tile buffers are indexed by
+    // GLOBAL band (local band + P n = `boff`), so the front item's band b and the back item's band b + P share a buffer exactly
+    // as two bands of one item do, and the same protocols (slot barrier, x1 counter) order their uses.
+    if (tid == 0) {
+        s_queue[0] = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_x1 = 0u; s_peek[0] = 0u; s_peek[1] = 0u; s_peekn = 0u;
+    }
+    const int P = A.P, q_last = (h + 37) / 10;                     // period in slots; last local slot with q rows inside the image
+    // Buffer descriptors: ONE over the fixed part of the workspace (both image planes, the guidance plane: the
+    // plane is chosen by a scalar offset), one over the hand-off records, one (per item) over the slice's q plane.
+    const unsigned fgw4 = ((unsigned)w + 2u * PADX) * 4u, w4 = (unsigned)w * 4u;
+    const rsrc_t r_fix = mk_rsrc(A.fix, A.fix_bytes);
+    const unsigned recb = (unsigned)(NI + 2) * REC_U * 16u;  // bytes per (parity, slice-view)  (smx_agg_v5.h records())
+    const rsrc_t r_hand = mk_rsrc(A.hand, (size_t)2 * nsv * recb);
+    {
         auto item_body = [&](auto ROLEc) {
         constexpr int ROLE = decltype(ROLEc)::value;
         constexpr bool ST2 = ROLE == ROLE_S2, COMB = ROLE <= ROLE_S2;
+        // ---- the item this role works on (set by `take`) ----------------------------------------------------------------
+        int item = 0, k = 0, sv = 0, view = 0, slice = 0, d = 0;
+        int base1 = 0;          // image column of tile-1 column 0
+        int base2 = 0;          // image column of tile-2 column 0 (= a/b column of the same comb lane)
+        bool pred = false, succ = false;
+        bool xedge = false;     // the strip has columns outside the image (virtual: -0)
+        unsigned* myflag = A.flags;
+        int o_fg1 = 0, o_fg2 = 0, o_g1p = 0, o_i2p = 0, o_i2b = 0, o_in = 0, o_out = 0;
+        rsrc_t r_q = r_fix;
+        // q rows: comb-ordered scratch (row y of this strip at (k h + y) * OWS) or the caller's [h][w]
+        int q_pitch = 0, q_row0 = 0;
+        auto decode = [&](int it) {
+            item = it;
+            k = it / nsv;
+            sv = it - k * nsv;
+            view = sv / A.nslices;
+            slice = sv - view * A.nslices;
+            base1 = OWS * k - 1;
+            base2 = OWS * k - R - 1;
+            pred = k > 0 && !(WHATIF & (64 | 4096)); succ = k + 1 < K && !(WHATIF & (64 | 2048));
+            d = A.d0[view] + slice;
+            myflag = A.flags + (size_t)sv * K + k;
+            o_fg1 = (int)A.o_fg[view]; o_fg2 = (int)A.o_fg[view ^ 1];
+            // this strip's rows of the comb-ordered guidance planes
+            // (band-major: 5 NI row pairs of 16 B per lane for stage 1; per band 16 B + 4 B per lane for stage 2 -- smx_agg_v5.h)
+            o_g1p = (int)(A.o_g1p[view] + (unsigned)k * (unsigned)(5 * NI) * (CLP * 16u));
+            o_i2p = (int)(A.o_i2p[view] + (unsigned)k * (unsigned)NI * (CLP * 16u));
+            o_i2b = (int)(A.o_i2p[view] + (unsigned)K * (unsigned)NI * (CLP * 16u) + (unsigned)k * (unsigned)NI * (CLP * 4u));
+            o_in = (int)((((unsigned)(k - 1) & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
+            o_out = (int)((((unsigned)k & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
+            r_q = mk_rsrc(A.q[view] + (size_t)slice * A.q_plane, A.q_plane * 4);
+            q_pitch = A.qperm ? OWS * 4 : (int)w4; q_row0 = A.qperm ? k * h * (OWS * 4) : 0;
+            xedge = base1 < 0 || base1 + SW > w;
+        };
         // the tile-2 buffer the comb rows of stage 1 write / the next scan pass takes for stage 2 and the hand-in fills,
         // and the stage-1 carries of that pass (they alternate from band to band)
         float* tile2 = tile2s[0];
         float (*cin1)[2] = cin1s[0];
         // ---- per-lane constants of the item that every comb row needs ------------------------------------------
         const int jt = comb_jt();                                   // tile column
-        int xw;                                                     // window width of this lane's output column
-        float rcp_i;                                                // 1 / (19 xw): interior rows
-        unsigned vo;                                                // stage 2: byte offset of the q column in a q row (stage 1: unused)
-        unsigned vg;                                                // byte offset of this lane in a row of the comb-ordered guidance plane
-        bool col_ok;
-        {
+        int xw = 1;                                                 // window width of this lane's output column
+        float rcp_i = 1.0f;                                         // 1 / (19 xw): interior rows
+        unsigned vo = OOB;                                          // stage 2: byte offset of the q column in a q row (stage 1: unused)
+        unsigned vg = 0;                                            // byte offset of this lane in a row of the comb-ordered guidance plane
+        bool col_ok = false;
+        f2 ca_i = {1.0f, 1.0f};                                     // interior rows: (1/area, area)
+        uint64_t okmask = 0;                                        // lanes with an output
+        const bool il0 = comb_il() == 0;
+        // stage 1: tile-2 column this lane's a_k, b_k go to -- its own tile column, or a padding column of the row when
+        // that column is the left neighbour's halo (lane 0 of a comb of a strip with a neighbour) or the lane idles
+        int jw = 0;
+        static_assert(SW + 16 <= P1 && P1 + SW + 16 <= RS, "padding columns behind both planes of a tile row");
+        auto lane_consts = [&]() {
             const int il = comb_il();
             const int xo = (ST2 ? base2 - R : base2) + jt;          // a/b column (stage 1) / q column (stage 2)
             col_ok = comb_rho() < HW && xo >= 0 && xo < w && (!ST2 || il >= 1);
@@ -333,20 +368,19 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 // one contiguous tail of its rows that the WTA pass never reads.
                 vo = !col_ok ? OOB : (A.qperm ? (unsigned)(k + 1 < K ? (L - 1) * comb_rho() + il - 1 : HW * (il - 1) + comb_rho()) * 4u : (unsigned)xo * 4u);
             }
-        }
-        const f2 ca_i = {rcp_i, (float)(HW * xw)};                       // interior rows: (1/area, area)
-        const uint64_t okmask = __builtin_amdgcn_ballot_w64(col_ok);     // lanes with an output
-        const bool il0 = comb_il() == 0;
-        // stage 1: tile-2 column this lane's a_k, b_k go to -- its own tile column, or a padding column of the row when
-        // that column is the left neighbour's halo (lane 0 of a comb of a strip with a neighbour) or the lane idles
-        const int jw = (comb_rho() < HW && !(pred && comb_il() == 0)) ? jt : SW + (lane & 15);
-        static_assert(SW + 16 <= P1 && P1 + SW + 16 <= RS, "padding columns behind both planes of a tile row");
+            ca_i = (f2){rcp_i, (float)(HW * xw)};
+            okmask = __builtin_amdgcn_ballot_w64(col_ok);
+            jw = (comb_rho() < HW && !(pred && comb_il() == 0)) ? jt : SW + (lane & 15);
+        };
 
         // ---- register state ------------------------------------------------------------------------------------
         f2 ring[COMB ? RD : 1];              // ring[y mod RD] = S[y] of this lane's column; the slot of row y-1 is the running sum
+        auto ring_reset = [&]() {
 #pragma unroll
-        for (int s = 0; s < (COMB ? RD : 1); ++s) ring[s] = (f2){0.0f, 0.0f};
-        if constexpr (COMB) ring[ST2 ? 10 : RD - 1] = NZ2;   // the slot in front of the first row (stage 1: row 0; stage 2: row -9)
+            for (int s = 0; s < (COMB ? RD : 1); ++s) ring[s] = (f2){0.0f, 0.0f};
+            if constexpr (COMB) ring[ST2 ? 10 : RD - 1] = NZ2;   // the slot in front of the first row (stage 1: row 0; stage 2: row -9)
+        };
+        ring_reset();
         // (arrays of the other role shrink to one element: the two roles are separate instantiations, so that no
         // register carries state of the other role around the band loop)
         // guidance of the band's output rows: loaded at the end of R (a barrier and the X1 phase ahead of the rows that
@@ -384,7 +418,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // load), byte offset in a tile, the row term alone and which of the four columns lie in the image (edge items).
         constexpr int CWN = ROLE == ROLE_COST ? NRQ : 1;
         unsigned cw_a1[CWN], cw_a2[CWN], cw_t[CWN], cw_rowb[CWN], cw_m[CWN];
-        if constexpr (ROLE == ROLE_COST) {
+        for (int r = 0; r < CWN; ++r) { cw_a1[r] = 0u; cw_a2[r] = 0u; cw_t[r] = 0u; cw_rowb[r] = 0u; cw_m[r] = 0u; }
+        auto cost_consts = [&]() {
+          if constexpr (ROLE == ROLE_COST) {
 #pragma unroll
             for (int r = 0; r < NRQ; ++r) {
                 int row, col; bool on;
@@ -402,7 +438,8 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 for (int j = 0; j < 4; ++j) m |= (base1 + col + j >= 0 && base1 + col + j < w) ? 1u << j : 0u;
                 cw_m[r] = (unsigned)opaque((int)(m | ((unsigned)row << 8)));     // (bits 8..: the tile row of the quad)
             }
-        }
+          }
+        };
         // ---- materialised cost volumes (the reference's calling convention, guidedFilter.cu:198-200: slice s of view v at
         // cost[v] + s * w * h): the cost wave LOADS the four costs of a quad instead of evaluating them; I p as before.
         // One descriptor per item over the slice plane.  A quad starts at column OWS k - 1 + 4 j: unaligned 16-byte loads (4-byte
@@ -411,12 +448,24 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // so that no window sum is negative, -0, tiny or non-finite -- is CHECKED here on every cost inside the image: the running
         // unsigned maximum of the bit patterns and minimum of (pattern - 1) per lane, compared once per item; a violation raises
         // the second status word, and the host has queued the ring walker behind this kernel to redo the chunk if it is set.
-        rsrc_t r_c = r_q;
+        rsrc_t r_c = r_fix;
         unsigned c_max = 0u, c_min1 = 0xffffffffu;
         const unsigned plane4 = (unsigned)(A.cost_plane * 4);
-        if constexpr (ROLE == ROLE_COST) {
-            if (A.src_cost) r_c = mk_rsrc(A.cost[view] + (size_t)slice * A.cost_plane, A.cost_plane * 4);
-        }
+        // (the cost wave's verdict on the item it leaves; then the descriptor of the new item's slice)
+        auto cost_verdict = [&]() {
+            if constexpr (ROLE == ROLE_COST) {
+                // a cost of the volume outside {+0} U [2^-60, 2^60] (negative, -0, denormal, tiny, huge, infinite, NaN): this
+                // kernel's results for the chunk do not count (smx_agg_v4.hip has queued the ring walker behind it)
+                if (A.src_cost && __builtin_amdgcn_ballot_w64(c_max > 0x5d800000u || c_min1 < 0x21800000u - 1u) != 0 && lane == 0)
+                    flag_store(A.bad, 1u);
+                c_max = 0u; c_min1 = 0xffffffffu;
+            }
+        };
+        auto cost_rsrc = [&]() {
+            if constexpr (ROLE == ROLE_COST) {
+                if (A.src_cost) r_c = mk_rsrc(A.cost[view] + (size_t)slice * A.cost_plane, A.cost_plane * 4);
+            }
+        };
         // edge items: byte offset of quad r of band ib clamped into the slice plane, and by how many elements it was moved
         auto cost_lin = [&](int ib, int r, int& linc4, int& sh) {
             const int row = (int)(cw_m[r] >> 8);
@@ -607,7 +656,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
 
         // ---- row scans of iteration i (wave 0): lanes 0..19 stage 1, lanes 32..51 stage 2; lane = (row, component)
         // stage 1: band i1 in tile t1p; stage 2: the a/b band i2 (rows 10 i2 - 9 ..) in tile t2p
-        auto rowscans = [&](int i1, int i2, float* t1p, float* t2p, float (*cinp)[2]) {
+        auto rowscans = [&](int i1, int i2, float* t1p, float* t2p, float (*cinp)[2], bool pred1, bool pred2) {
             const int sc_l = lane & 31, sc_st = lane >> 5, sc_row = sc_l % BH, sc_comp = sc_l / BH;
             const bool sc_on = sc_l < 2 * BH;
             const int y = sc_st == 0 ? BH * i1 + sc_row : BH * i2 - R + sc_row;
@@ -616,8 +665,9 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             float* const row = (sc_st == 0 ? t1p : t2p) + sc_row * RS + sc_comp * P1;
             // stage 1 starts from the left neighbour's running row sum (or -0); stage 2 of a strip with a left
             // neighbour leaves the 19 halo columns alone and starts behind them from the halo's last column
-            const bool keep = sc_st == 1 && pred;
-            float acc = (sc_st == 0 && pred) ? cinp[sc_row][sc_comp] : -0.0f;
+            // (pred1 / pred2: the item of the stage-1 / stage-2 lanes has a left neighbour -- two items in an overlap slot)
+            const bool keep = sc_st == 1 && pred2;
+            float acc = (sc_st == 0 && pred1) ? cinp[sc_row][sc_comp] : -0.0f;
             f4* const r4 = (f4*)row;
             constexpr int NG = SW / 4;
 #ifndef SMX_V5_SCAN_PF
@@ -840,68 +890,57 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         };
 
         // ===================================== the slot loop: the row scans run beside the comb rows =======================
-        // Scan pass s (s = -1 .. NI-2) = stage-1 band s+1 and the a/b band s-1, by the scan wave during slot s; slot s also
-        // has the comb rows of stage 1 on band s (scanned in pass s-1) and of stage 2 on the a/b band s-2 (scanned in pass
-        // s-1, taken out of its tile at the start of the slot), and the cost wave's band s+2.  ONE workgroup barrier per slot.
-        // Stage-1 band b lives in tile1[b mod 3], the a/b band b in tile2s[b mod 2], the carries of pass s in
-        // cin1s[s mod 2].  The hand-off record of pass s -- {carries of band s+1, halo of the a/b band s-1} -- has index s+1.
-        auto T1 = [&](int b) { return tile1[(b + 3) % 3]; };
-        auto T2 = [&](int b) { return tile2s[(b + 2) & 1]; };
-        auto CI = [&](int sp) { return cin1s[(sp + 2) & 1]; };
-        if (pred) {
-            if (tid == 0) spin_pred(1u);
-            wg_barrier();
-            seen = s_seen;
-        }
-        have_pref = pred;
-        if constexpr (ROLE == ROLE_S1) {
-            fetch_rec(0);
-            g1_load(0, std::integral_constant<int, 0>{});
-            g1_load(1, std::integral_constant<int, 1>{});
-            if (pred) { cin1 = CI(-1); hand_in(false, hreg); }
-        }
-        if constexpr (ROLE == ROLE_COST) {
-            eval_band_p(0, T1(0));
-        }
-        auto slot = [&](auto PARc, int sl) {
+        // Scan pass s (s = -1 .. ) = stage-1 band s+1 and the a/b band s-1, by the scan wave during slot s; slot s also has the
+        // comb rows of stage 1 on band s (scanned in pass s-1) and of stage 2 on the a/b band s-2 (scanned in pass s-1, taken out
+        // of its tile at the start of the slot), and the cost wave's band s+2.  ONE workgroup barrier per slot.
+        // Stage-1 band b lives in tile1[gb mod 3], the a/b band b in tile2s[gb mod 2], the carries of pass s in cin1s[gs mod 2]
+        // with gb = b + (global band of the item's band 0).  The hand-off record of pass s -- {carries of band s+1, halo of the
+        // a/b band s-1} -- has index s+1.
+        // The buffers by GLOBAL band, relative to the band gb of the current global slot (gb = local slot + the item's band 0; it
+        // advances by one per slot across item boundaries, whichever item a role is on): G1[j] = tile 1 of band gb + j,
+        // G2[j] = tile 2 of band gb - j, GC[j] = the carries of pass gb + j.  Rotated at the end of every slot: no modulo
+        // arithmetic in the loop (the first pipelined build spent 60 % more scalar instructions than the per-item loop).
+        float* G1[3] = {tile1[1], tile1[2], tile1[0]};                 // gb = -2 at the first slot: (gb + 6) % 3 = 1
+        float* G2[2] = {tile2s[0], tile2s[1]};                         // (gb + 6) & 1 = 0; band gb - 1: 1
+        float (*GC[2])[2] = {cin1s[0], cin1s[1]};
+        int g = 0;                  // global slot of this workgroup
+        int nf = 0;                 // items the front roles have started
+        int slf = -2;               // local slot of the front item (-2 .. P-3)
+        bool ending = false;        // no ticket left: the front roles idle while stage 2 finishes the last item
+        bool f_pred = false;        // the front item has a left neighbour (every wave tracks it: the flag wait has a barrier in it)
+        bool own = false;           // this role has an item
+        // stage 2 moves to the front item in front slot 1: the back item's last q rows left in front slot q_last - P <= 0, and
+        // its own first slot on an item is 1 (a fixed slot keeps the item's state invariant in the main slot loop below)
+        constexpr int sw = 1;
+        int pend_item = 0; bool pend = false;                   // (stage 2) the front item, taken over at slot sw
+        bool b_pred = false, b_own = false;                     // (scan wave) the back item: its a/b band P-3 is scanned in front slot -2
+        int nxt = 0;                                            // (cost wave, lane 63) the ticket after the front item's
+
+        // ---- stage 1: one slot of its item (sl = -2: the first record and the first guidance pairs; -1: a record; >= 0: rows)
+        auto slot_s1 = [&](auto PARc, int sl) {
             constexpr int PAR = decltype(PARc)::value;
-            [[maybe_unused]] const int i = sl;          // (V5_STAMP)
-            wg_barrier();
-            V5_STAMP(0);
-            V5_STAMP(1);
-            V5_STAMP(2);
-            if constexpr (ROLE >= ROLE_SCAN) { V5_STAMP(3); V5_STAMP(4); }
-            // every wave must come to the same `seen` (the wait below has a barrier in it): the peek of the previous slot, written
-            // before the barrier above and not touched during this slot; flags only grow, so a stale entry is harmless
-            seen = max(seen, s_peek[sl & 1]);
-            if constexpr (ROLE == ROLE_SCAN) {
-                if (!(WHATIF & 1024) && A.prio) __builtin_amdgcn_s_setprio(PRIO_SCAN);
-                V5_MARK("scan begin");
-                if (!(WHATIF & 1) && sl + 1 < NI) rowscans(sl + 1, sl - 1, T1(sl + 1), T2(sl - 1), CI(sl));
-                V5_MARK("scan end");
-                __builtin_amdgcn_s_setprio(0);
-            } else if constexpr (ROLE == ROLE_COST) {
-                if (lane == 63) {
-                    // an otherwise idle lane looks at the left neighbour's flag for the prefetch of the next record
-                    if (pred && seen != FLAG_DONE && seen < (unsigned)sl + 4u) s_peek[(sl + 1) & 1] = flag_load(myflag - 1);
-                    // ticket of the next item, one slot before the end
-                    if (sl == NI - 1)
-                        s_next = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                if (A.prio) __builtin_amdgcn_s_setprio(PRIO_COST);
-                if (!(WHATIF & 2) && sl + 2 < NI) eval_band_p(sl + 2, T1(sl + 2));
-                __builtin_amdgcn_s_setprio(0);
-            } else if constexpr (ROLE == ROLE_S1) {
+            [[maybe_unused]] const int i = g;           // (V5_STAMP)
+            if constexpr (ROLE == ROLE_S1) {
                 // the record of pass sl+1 is needed at the end of this slot: its load goes out now (unconditionally);
                 // what it returns counts only if the record had been published
                 fetch_rec(min(sl + 2, NI - 1));
+                if (sl == -2) {
+                    g1_load(0, std::integral_constant<int, 0>{});
+                    g1_load(1, std::integral_constant<int, 1>{});
+                }
                 if (sl >= 0) {
-                    const float* const t1 = T1(sl);
+                    const float* const t1 = G1[0];
                     f2 rv = tile_rd(t1 + jt);
-                    tile2 = T2(sl);
+                    tile2 = G2[0];
                     V5_STAMP(3);
+                    if (sl == 0 && succ && tid < NCU) {
+                        // record 0 (the stage-1 row carries of band 0; no halo yet) leaves from HERE: stage 2 is still on the
+                        // item before this one.  It is drained at the end of this slot and published by stage 2 in the next.
+                        const float* p = t1 + 2 * tid * RS + OWS - 1;
+                        st16_sc1(r_hand, (unsigned)o_out + (unsigned)(NHU + tid) * 16u, (f4){p[0], p[P1], p[RS], p[RS + P1]});
+                    }
                     if (A.prio) __builtin_amdgcn_s_setprio(PRIO_S1);
-                    x1_need = (unsigned)NS1 * (unsigned)(sl + 1);
+                    x1_need = (unsigned)NS1 * (unsigned)(g + 1);
                     const bool border = BH * sl - R < R + 1 || BH * sl - R + BH - 1 > h - 1 - R;
                     if (WHATIF & 4) wait_x1();                  // (the rows wait in front of their first store)
                     V5_STAMP(4);
@@ -917,122 +956,239 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
 #undef V5_P1
 #undef V5_P1E
 #undef V5_P1B
-#ifndef SMX_V5_PRIO_S1TAIL
                     __builtin_amdgcn_s_setprio(0);
-#endif
                     V5_STAMP(11);
                 }
-            } else {
-                if (sl >= 0) {
-                    if (succ && tid == 64 * 2 * NS1 - 1 && sl >= 1) flag_store(myflag, (unsigned)sl);
-                    // the a/b band sl-2 (scanned in pass sl-1) out of its tile; the record of pass sl-1 (index sl): halo of that
-                    // band, carries of stage-1 band sl
-                    if (A.prio) __builtin_amdgcn_s_setprio(PRIO_S2HEAD);      // (the stage-1 waves are waiting for this copy-out)
-                    V5_MARK("s2head begin");
-                    const float* const t2 = T2(sl);
+            }
+        };
+        // ---- stage 2: one slot (1 <= sl <= q_last) of its item: the a/b band sl-2 out of its tile, record sl out, q rows
+        auto slot_s2 = [&](auto PARc, int sl) {
+            constexpr int PAR = decltype(PARc)::value;
+            [[maybe_unused]] const int i = g;           // (V5_STAMP)
+            if constexpr (ST2) {
+                if (succ && tid == 64 * 2 * NS1 - 1) flag_store(myflag, (unsigned)sl);     // records 0 .. sl-1 are complete
+                // the a/b band sl-2 (scanned in pass sl-1) out of its tile; the record of pass sl-1 (index sl): halo of that
+                // band, carries of stage-1 band sl
+                if (A.prio) __builtin_amdgcn_s_setprio(PRIO_S2HEAD);      // (the stage-1 waves are waiting for this copy-out)
+                V5_MARK("s2head begin");
+                const float* const t2 = G2[0];
 #pragma unroll
-                    for (int t = 0; t < BH; ++t) r2[t] = tile_rd(t2 + t * RS + jt);
-                    const int hq = hu_idx();
-                    const bool rec_out = succ && hq >= 0 && hq < REC_U;
-                    f4 hov = {0.0f, 0.0f, 0.0f, 0.0f};
-                    if (rec_out) {
-                        if (hq < NHU) {
-                            const int t = hq / 10, j = (hq - 10 * t) * 2;
-                            const float* p = t2 + t * RS + OWS + j;
-                            hov = (f4){p[0], p[P1], p[1], p[P1 + 1]};
-                        } else {
-                            const float* p = T1(sl) + 2 * (hq - NHU) * RS + OWS - 1;
-                            hov = (f4){p[0], p[P1], p[RS], p[RS + P1]};
-                        }
+                for (int t = 0; t < BH; ++t) r2[t] = tile_rd(t2 + t * RS + jt);
+                const int hq = hu_idx();
+                const bool rec_out = succ && hq >= 0 && hq < REC_U;
+                f4 hov = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (rec_out) {
+                    if (hq < NHU) {
+                        const int t = hq / 10, j = (hq - 10 * t) * 2;
+                        const float* p = t2 + t * RS + OWS + j;
+                        hov = (f4){p[0], p[P1], p[1], p[P1 + 1]};
+                    } else {
+                        const float* p = G1[0] + 2 * (hq - NHU) * RS + OWS - 1;
+                        hov = (f4){p[0], p[P1], p[RS], p[RS + P1]};
                     }
-                    // everything this wave needs from tile 2 is in registers: tell the stage-1 waves at once (they are waiting to
-                    // overwrite the tile); the record goes to memory behind that
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r2[0]), "+v"(r2[1]), "+v"(r2[2]), "+v"(r2[3]), "+v"(r2[4]), "+v"(r2[5]),
-                                 "+v"(r2[6]), "+v"(r2[7]), "+v"(r2[8]), "+v"(r2[9]), "+v"(hov) :: "memory");
-                    if (lane == 0) __hip_atomic_fetch_add(&s_x1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (rec_out) st16_sc1(r_hand, (unsigned)(o_out + sl * REC_U * 16) + (unsigned)hq * 16u, hov);
-                    V5_MARK("s2head end");
-                    __builtin_amdgcn_s_setprio(0);
-                    V5_STAMP(3);
-                    V5_STAMP(4);
-                    [[maybe_unused]] bool s2_interior = false;
-                    if (sl >= 2) {
-                        const int yq0 = BH * (sl - 2) - 2 * R;
-                        const bool border = yq0 < R + 1 || yq0 + BH - 1 > h - 1 - R;
-                        s2_interior = !border && !(WHATIF & (8 | 16 | 32));
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (!(WHATIF & 8)) {
+                }
+                // everything this wave needs from tile 2 is in registers: tell the stage-1 waves at once (they are waiting to
+                // overwrite the tile); the record goes to memory behind that
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r2[0]), "+v"(r2[1]), "+v"(r2[2]), "+v"(r2[3]), "+v"(r2[4]), "+v"(r2[5]),
+                             "+v"(r2[6]), "+v"(r2[7]), "+v"(r2[8]), "+v"(r2[9]), "+v"(hov) :: "memory");
+                if (lane == 0) __hip_atomic_fetch_add(&s_x1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (rec_out) st16_sc1(r_hand, (unsigned)(o_out + sl * REC_U * 16) + (unsigned)hq * 16u, hov);
+                // a/b rows behind the image are -0 (stage 1 writes them as long as it is on this item; in the last slots of an
+                // item it has moved on, and the tile holds an older band)
+                if (BH * (sl - 2) - R + BH - 1 >= h) {          // (only in the last slots of an item)
+#pragma unroll
+                    for (int t = 0; t < BH; ++t)
+                        if (BH * (sl - 2) - R + t >= h) r2[t] = NZ2;
+                }
+                V5_MARK("s2head end");
+                __builtin_amdgcn_s_setprio(0);
+                V5_STAMP(3);
+                V5_STAMP(4);
+                [[maybe_unused]] bool s2_interior = false;
+                if (sl >= 2) {
+                    const int yq0 = BH * (sl - 2) - 2 * R;
+                    const bool border = yq0 < R + 1 || yq0 + BH - 1 > h - 1 - R;
+                    s2_interior = !border && !(WHATIF & (8 | 16 | 32)) && sl != q_last;
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (!(WHATIF & 8)) {
 #define V5_P2(TT) rows2_pair(std::integral_constant<int, BH * PAR + TT>{}, std::false_type{}, sl);
 #define V5_P2B(TT) rows2_pair(std::integral_constant<int, BH * PAR + TT>{}, std::true_type{}, sl);
-                        if (border) { rcb = rcp_pair(yq0); V5_P2B(0) V5_STAMP(6); V5_P2B(2) V5_STAMP(7); V5_P2B(4) V5_STAMP(8); V5_P2B(6) V5_STAMP(9); V5_P2B(8) V5_STAMP(10); }
-                        else { V5_MARK("s2rows begin"); V5_P2(0) V5_STAMP(6); V5_P2(2) V5_STAMP(7); V5_P2(4) V5_STAMP(8); V5_P2(6) V5_STAMP(9); V5_P2(8) V5_STAMP(10); V5_MARK("s2rows end"); }
-                        }
+                    if (border) { rcb = rcp_pair(yq0); V5_P2B(0) V5_STAMP(6); V5_P2B(2) V5_STAMP(7); V5_P2B(4) V5_STAMP(8); V5_P2B(6) V5_STAMP(9); V5_P2B(8) V5_STAMP(10); }
+                    else { V5_MARK("s2rows begin"); V5_P2(0) V5_STAMP(6); V5_P2(2) V5_STAMP(7); V5_P2(4) V5_STAMP(8); V5_P2(6) V5_STAMP(9); V5_P2(8) V5_STAMP(10); V5_MARK("s2rows end"); }
+                    }
 #undef V5_P2
 #undef V5_P2B
+                }
+                issue_guid(sl, BH * (sl - 1) - 2 * R);
+                // the record stored above is complete in memory before the barrier behind which it is published
+                // (vector-memory operations of a wave complete in issue order: what was issued behind the record store -- the
+                // ten q rows of an interior band and the two guidance loads -- may stay in flight; -DSMX_V5_S2_KEEP=0: the
+                // full drain of round 4; the item's last slot drains everything: FLAG_DONE follows)
+                if (S2_KEEP > 0 && s2_interior) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(S2_KEEP) : "memory"); else
+                drain_vmem();
+            }
+        };
+
+        // One global slot.  The period P is EVEN (smx_agg_v5.h period()), so the local slot of every role's item has the parity of the
+        // global slot: the loop below alternates the two parities statically (the register rings and the guidance ring use
+        // static slots per parity; a run-time dispatch would put loads under a condition -- they are then waited for where the
+        // branches merge: measured, +13 %).  Returns true when the workgroup is done.
+        auto iter = [&](auto PARc) -> bool {
+            wg_barrier();
+            [[maybe_unused]] const int i = g;           // (V5_STAMP: by global slot)
+            V5_STAMP(0); V5_STAMP(1); V5_STAMP(2);
+            if constexpr (ROLE >= ROLE_SCAN) { V5_STAMP(3); V5_STAMP(4); }
+            if (slf == -2) {
+                // ---- a new front item (or none) -----------------------------------------------------------------------------
+                const int it = s_queue[nf & 3];
+                ending = it >= A.nitems;
+                if (ending && nf == 0) return true;     // (a workgroup without any ticket)
+                f_pred = !ending && it / nsv > 0 && !(WHATIF & (64 | 4096));
+                // every wave must come to the same `seen` (the wait below has a barrier in it): what the cost wave peeked at in
+                // the slot before, for THIS item
+                seen = nf > 0 ? s_peekn : 0u;
+                if constexpr (ROLE == ROLE_COST) {
+                    if (own) cost_verdict();
+                    own = !ending;
+                    if (own) { decode(it); cost_consts(); cost_rsrc(); }
+                } else if constexpr (ROLE == ROLE_S1) {
+                    own = !ending;
+                    if (own) {
+                        decode(it); lane_consts(); ring_reset();
+                        gr[0] = (f4){0, 0, 0, 0}; gr[1] = (f4){0, 0, 0, 0};
                     }
-                    issue_guid(sl, BH * (sl - 1) - 2 * R);
-                    // the record stored above is complete in memory before the barrier behind which it is published
-                    // (vector-memory operations of a wave complete in issue order: what was issued behind the record store -- the
-                    // ten q rows of an interior band and the two guidance loads -- may stay in flight; -DSMX_V5_S2_KEEP=0: the
-                    // full drain of round 4)
-                    if (S2_KEEP > 0 && s2_interior) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(S2_KEEP) : "memory"); else
-                    drain_vmem();
+                } else if constexpr (ROLE == ROLE_SCAN) {
+                    b_pred = pred; b_own = own;
+                    own = !ending;
+                    if (own) decode(it);
+                } else {
+                    pend_item = it; pend = !ending;
+                }
+            } else {
+                // (the peek of the previous slot, written before the barrier above; the cost wave writes it every slot)
+                seen = max(seen, s_peek[g & 1]);
+            }
+            if constexpr (ST2) {
+                if (slf == sw) {
+                    // the item stage 2 leaves is complete: its last record and q rows were drained at the end of its last slot
+                    if (own && succ && tid == 64 * 2 * NS1 - 1) flag_store(myflag, FLAG_DONE);
+                    own = pend;
+                    if (own) {
+                        decode(pend_item); lane_consts(); ring_reset();
+#pragma unroll
+                        for (int t = 0; t < BH; ++t) r2[t] = NZ2;
+                    }
                 }
             }
-            // ---- hand-in of the record of pass sl+1 (index sl+2), prefetched at the top of the slot if it had been published
-            have_pref = pred && (seen == FLAG_DONE || seen >= (unsigned)sl + 3u);
-            // (two copies of the hand-in on purpose: the prefetched record is OLDER than the guidance loads of this slot, so its
-            // wait leaves those in flight; a record fetched again behind the flag wait is the newest load, and one merged copy
-            // would wait for everything -- it did: every stage-1 wave sat out its five guidance loads in front of the slot barrier)
-            if (pred && !have_pref && sl + 2 < NI) {
-                if (tid == 0) spin_pred((unsigned)sl + 3u);
+            // ---- the slot's work ----------------------------------------------------------------------------------------
+            if constexpr (ROLE == ROLE_SCAN) {
+                if (!(WHATIF & 1024) && A.prio) __builtin_amdgcn_s_setprio(PRIO_SCAN);
+                V5_MARK("scan begin");
+                if (!(WHATIF & 1)) {
+                    const int i1 = own && slf + 1 < NI ? slf + 1 : -1;
+                    // (front slot -2: the back item's last a/b band with rows inside the image can still be waiting, P == s1_last + 3;
+                    // it is the band in front of this global slot's like any other)
+                    const int i2 = slf == -2 ? (b_own ? P - 3 : -1) : (own ? slf - 1 : -1);
+                    rowscans(i1, i2, G1[1], G2[1], GC[0], pred, slf == -2 ? b_pred : pred);
+                }
+                V5_MARK("scan end");
+                __builtin_amdgcn_s_setprio(0);
+            } else if constexpr (ROLE == ROLE_COST) {
+                if (lane == 63) {
+                    // an otherwise idle lane looks at the left neighbour's flag for the prefetch of the next record (written every
+                    // slot: a stale entry could belong to the item before)
+                    unsigned pk = 0u;
+                    if (own && pred && seen != FLAG_DONE && seen < (unsigned)(slf + 4)) pk = flag_load(myflag - 1);
+                    s_peek[(g + 1) & 1] = pk;
+                    // the ticket after this item's, a few slots before the front roles need it
+                    if (own && slf == (P >= 8 ? P - 6 : -2)) {
+                        nxt = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_queue[(nf + 1) & 3] = nxt;
+                    }
+                    // ... and, in the last slot of this item, the flag of THAT item's left neighbour for its first slot
+                    if (own && slf == P - 3) {
+                        unsigned pn = 0u;
+                        if (nxt < A.nitems) {
+                            const int kn = nxt / nsv, svn = nxt - kn * nsv;
+                            if (kn > 0 && !(WHATIF & (64 | 4096))) pn = flag_load(A.flags + (size_t)svn * K + kn - 1);
+                        }
+                        s_peekn = pn;
+                    }
+                }
+                if (A.prio) __builtin_amdgcn_s_setprio(PRIO_COST);
+                if (own && !(WHATIF & 2) && slf + 2 < NI) eval_band_p(slf + 2, G1[2]);
+                __builtin_amdgcn_s_setprio(0);
+            } else if constexpr (ROLE == ROLE_S1) {
+                if (own) slot_s1(PARc, slf);
+            } else {
+                const int sl = slf >= sw ? slf : slf + P;           // local slot of stage 2's own item
+                if (own && sl >= 1 && sl <= q_last) {
+                    slot_s2(PARc, sl);
+                } else if (lane == 0) {
+                    // (no copy-out in this slot: the stage-1 waves count one per global slot all the same)
+                    __hip_atomic_fetch_add(&s_x1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+            // ---- hand-in of the FRONT item's record of pass slf+1 (index slf+2), prefetched at the top of the slot if it had been
+            // published.  (two copies of the hand-in on purpose: the prefetched record is OLDER than the guidance loads of this slot,
+            // so its wait leaves those in flight; a record fetched again behind the flag wait is the newest load, and one merged
+            // copy would wait for everything)
+            have_pref = f_pred && (seen == FLAG_DONE || seen >= (unsigned)(slf + 3));
+            if (f_pred && !have_pref && slf + 2 < NI) {
+                if (tid == 0) spin_pred((unsigned)(slf + 3));
                 wg_barrier();
                 seen = s_seen;
                 if constexpr (ROLE == ROLE_S1) {
                     const int hq = hu_idx();
-                    const f4 late = ld16_sc1(r_hand, (unsigned)(o_in + min(sl + 2, NI - 1) * REC_U * 16) + (hq >= 0 && hq < REC_U ? (unsigned)hq * 16u : 0u));
-                    cin1 = CI(sl + 1); tile2 = T2(sl);
-                    hand_in(sl >= 0, late);
+                    const f4 late = ld16_sc1(r_hand, (unsigned)(o_in + min(slf + 2, NI - 1) * REC_U * 16) + (hq >= 0 && hq < REC_U ? (unsigned)hq * 16u : 0u));
+                    cin1 = GC[1]; tile2 = G2[0];
+                    hand_in(slf >= 0, late);
                 }
             } else if constexpr (ROLE == ROLE_S1) {
-                // (the halo is that of the a/b band sl, which the comb rows above have just written into the same tile)
+                // (the halo is that of the a/b band slf, which the comb rows above have just written into the same tile)
                 V5_MARK("s1handin begin");
-                if (pred && sl + 2 < NI) { cin1 = CI(sl + 1); tile2 = T2(sl); hand_in(sl >= 0, hreg); }
+                if (own && pred && slf + 2 < NI) { cin1 = GC[1]; tile2 = G2[0]; hand_in(slf >= 0, hreg); }
                 V5_MARK("s1handin end");
             }
             if constexpr (ROLE == ROLE_S1) {
-                if (sl >= 0) g1_load(5 * sl + 6, std::integral_constant<int, PAR>{});     // (pair 4 of this slot used entry (PAR + 4) & 1)
-#ifdef SMX_V5_PRIO_S1TAIL
-                __builtin_amdgcn_s_setprio(0);
-#endif
+                // (pair 4 of this slot used ring entry (parity + 4) & 1 = parity.  Unconditional: in the two slots in front of the
+                // rows it re-loads the pair the entry holds already -- pair 0 in slot -2, pair 1 in slot -1 -- and with no item it
+                // is harmless)
+                g1_load(slf >= 0 ? 5 * slf + 6 : slf + 2, PARc);
+                if (own && slf == 0 && succ) drain_vmem();      // record 0 (see slot_s1) is in memory before the next barrier
             }
             V5_STAMP(5);
+            if (ending && slf == 1) return true;
+            { float* const t = G1[0]; G1[0] = G1[1]; G1[1] = G1[2]; G1[2] = t; }
+            { float* const t = G2[0]; G2[0] = G2[1]; G2[1] = t; }
+            { float (*const t)[2] = GC[0]; GC[0] = GC[1]; GC[1] = t; }
+            ++g;
+            return false;
         };
-        slot(std::integral_constant<int, 1>{}, -1);
-        for (int sl = 0; sl < NI; sl += 2) {
-            slot(std::integral_constant<int, 0>{}, sl);
-            if (sl + 1 < NI) slot(std::integral_constant<int, 1>{}, sl + 1);
+        // Per front item: four slots in which items change hands (-2: the front roles; 1: stage 2), then the main loop over
+        // slots 2 .. P-3, in which every role's item state is loop-invariant (the compiler hoists what it derives from it: a
+        // single loop over all slots cost 60 % more scalar instructions).  P is even: P - 4 slots in the main loop.
+        for (;;) {
+            bool done = false;
+            for (slf = -2; slf < 2 && !done; slf += 2) {
+                done = iter(std::integral_constant<int, 0>{});
+                if (!done) { ++slf; done = iter(std::integral_constant<int, 1>{}); --slf; }
+            }
+            if (done) break;
+            for (slf = 2; slf <= P - 3; slf += 2) {
+                (void)iter(std::integral_constant<int, 0>{});
+                ++slf;
+                (void)iter(std::integral_constant<int, 1>{});
+                --slf;
+            }
+            ++nf;
         }
-        if constexpr (ROLE == ROLE_COST) {
-            // a cost of the volume outside {+0} U [2^-60, 2^60] (negative, -0, denormal, tiny, huge, infinite, NaN): this
-            // kernel's results for the chunk do not count (smx_agg_v4.hip has queued the ring walker behind it)
-            if (A.src_cost && __builtin_amdgcn_ballot_w64(c_max > 0x5d800000u || c_min1 < 0x21800000u - 1u) != 0 && lane == 0)
-                flag_store(A.bad, 1u);
-        }
+        if constexpr (ROLE == ROLE_COST) { if (own) cost_verdict(); }
         };
-        if (tid == 0) { s_x1 = 0u; s_peek[0] = 0u; s_peek[1] = 0u; }   // (ordered before the first use by the barrier at the top of the first band)
-        // (the cost wave's verdict on a materialised cost volume is raised inside item_body, below the slot loop)
         if (wave < NS1) item_body(std::integral_constant<int, ROLE_S1>{});
         else if (wave < 2 * NS1) item_body(std::integral_constant<int, ROLE_S2>{});
         else if (wave == 2 * NS1) item_body(std::integral_constant<int, ROLE_SCAN>{});
         else item_body(std::integral_constant<int, ROLE_COST>{});
-        // the last record and the last q rows: drained, then published
-        drain_vmem();
-        wg_barrier();
-        if (tid == 0) {
-            if (succ) flag_store(myflag, FLAG_DONE);
-            s_item = s_next;
-        }
     }
 }
 

@@ -1,6 +1,8 @@
-"""Per-wave phase timeline of one work item of k_v5_walk (diagnostic build:
-tools/exp_build.sh stamps5 -DSMX_V5_STAMPS=<item>).  Slots per iteration: start / end of the work of the W, R and X
-phases (the gaps are barrier waits)."""
+"""Per-wave phase timeline of one WORKGROUP of k_v5_walk over 48 of its global slots (diagnostic build:
+tools/exp_build.sh stamps5 -DSMX_V5_STAMPS=<workgroup> [-DSMX_V5_STAMP_G0=<first global slot>]; since the items of a workgroup are
+pipelined a slot no longer belongs to one item).  Slots per iteration: start / end of the work of the W, R and X phases (the
+gaps are barrier waits).  The stamps themselves cost more than in round 4 (every wave of every workgroup evaluates their
+condition): use them for the shape of a slot, not for its length."""
 import ctypes as C, os, sys
 import numpy as np
 import torch
