@@ -1576,7 +1576,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                 b.d0[v] = a.v[vv].d0;
             }
             b.w = w; b.h = h; b.K = L.K; b.NI = L.NI;
-            b.P = v5::period(h);
+            b.P = v5::period(h, L.K);
             b.nslices = a.nslices; b.nsv = a.nsv; b.nitems = a.nitems;
             b.hand = (float*)hand; b.flags = a.flags; b.ticket = a.ticket; b.status = a.status;
             b.src_cost = use_cost ? 1 : 0;

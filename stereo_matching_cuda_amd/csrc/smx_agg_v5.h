@@ -59,10 +59,23 @@ inline int records(int h) { return bands(h) + 2; }                   // hand-off
 // -2 .. s1_last (s1_last = the slot of the last a/b row inside the image), stage 2 for 1 .. q_last (the last q row).  A
 // workgroup starts its next item after period(h) slots: the longest of those ranges (bands(h) - 1 or bands(h)), at least 4,
 // rounded up to an even number.
-inline int period(int h) {
+inline int period(int h, int K) {
     const int s1_last = (h + 8) / 10, q_last = (h + 37) / 10;
     int p = s1_last + 3 > q_last ? s1_last + 3 : q_last;
-    p = p < 4 ? 4 : p;
+    // NO DEADLOCK needs p >= 2 K + 2 (and >= 6); the argument is spelled out in DESIGN.md 4.1.  While a workgroup runs slots
+    // -2 .. 0 of its next item x' it may wait for flags 1 .. 3 of that item's left neighbour, and until it is through them
+    // the LAST records of the item x it is finishing stay unpublished: late(x) <- early(pred(x')), a dependency on a LARGER
+    // ticket.  Two things keep the wait-for graph acyclic all the same: (1) a wait on such a late record happens in slots
+    // >= p - 4 of the waiter, and from a workgroup in slots -2 / -1 a chain of waits through left neighbours in the same row
+    // (2 slots of lag per strip, at most K - 2 of them) reaches slot 2 K - 5 < p - 4 at most, so between two late waits a
+    // cycle passes a workgroup that has not even STARTED the awaited item; (2) tickets are taken in slot p - 6 >= 0, behind a
+    // flag wait, so a left neighbour's workgroup takes its next ticket before the right neighbour's does.  With both, the
+    // largest ticket among the items of a cycle cannot be reached again by walking the cycle.  (h = 9, p = 4: two workgroups
+    // waited for each other's last records; caught by the bounded wait,
+    // tests/test_gpu_parity.py::test_items_pipelined_across_a_workgroups_tickets.)  Short or wide-and-short images get a
+    // period of the whole item: nothing overlaps, an item's completion is published before its workgroup waits for anything
+    // of the next one, and every wait points to a smaller ticket.
+    if (p < 6 || p < 2 * K + 2) p = bands(h) + 2;
     return p + (p & 1);     // even: the local slot of an item then has the parity of the workgroup's global slot (static ring slots)
 }
 inline size_t sv_hand_floats(int h) { return (size_t)2 * records(h) * REC_U * 4; }   // parity x records

@@ -913,6 +913,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         // its own first slot on an item is 1 (a fixed slot keeps the item's state invariant in the main slot loop below)
         constexpr int sw = 1;
         int pend_item = 0; bool pend = false;                   // (stage 2) the front item, taken over at slot sw
+        int sl2 = 0;                                            // (stage 2) local slot of its own item
         bool b_pred = false, b_own = false;                     // (scan wave) the back item: its a/b band P-3 is scanned in front slot -2
         int nxt = 0;                                            // (cost wave, lane 63) the ticket after the front item's
 
@@ -1069,10 +1070,13 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 seen = max(seen, s_peek[g & 1]);
             }
             if constexpr (ST2) {
+                // the slot behind an item's last one: the item is complete (its last record and q rows were drained at the end of
+                // that slot, the barrier above lies in between) -- published NOW, before this slot's work and its flag wait: an
+                // item's completion must not hang on the progress of the workgroup's next item any longer than its last rows do
+                if (own && sl2 == q_last + 1 && succ && tid == 64 * 2 * NS1 - 1) flag_store(myflag, FLAG_DONE);
                 if (slf == sw) {
-                    // the item stage 2 leaves is complete: its last record and q rows were drained at the end of its last slot
-                    if (own && succ && tid == 64 * 2 * NS1 - 1) flag_store(myflag, FLAG_DONE);
                     own = pend;
+                    sl2 = sw;
                     if (own) {
                         decode(pend_item); lane_consts(); ring_reset();
 #pragma unroll
@@ -1100,8 +1104,10 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     unsigned pk = 0u;
                     if (own && pred && seen != FLAG_DONE && seen < (unsigned)(slf + 4)) pk = flag_load(myflag - 1);
                     s_peek[(g + 1) & 1] = pk;
-                    // the ticket after this item's, a few slots before the front roles need it
-                    if (own && slf == (P >= 8 ? P - 6 : -2)) {
+                    // the ticket after this item's, a few slots before the front roles need it -- and never in the item's first
+                    // slot when items overlap (P >= 6 then): behind the flag wait of slot -1 the left neighbour's workgroup has
+                    // taken ITS next ticket already, and the deadlock-freedom argument needs that order
+                    if (own && slf == P - 6) {
                         nxt = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         s_queue[(nf + 1) & 3] = nxt;
                     }
@@ -1121,7 +1127,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             } else if constexpr (ROLE == ROLE_S1) {
                 if (own) slot_s1(PARc, slf);
             } else {
-                const int sl = slf >= sw ? slf : slf + P;           // local slot of stage 2's own item
+                const int sl = sl2;                                 // local slot of stage 2's own item
                 if (own && sl >= 1 && sl <= q_last) {
                     slot_s2(PARc, sl);
                 } else if (lane == 0) {
@@ -1163,6 +1169,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             { float* const t = G2[0]; G2[0] = G2[1]; G2[1] = t; }
             { float (*const t)[2] = GC[0]; GC[0] = GC[1]; GC[1] = t; }
             ++g;
+            ++sl2;
             return false;
         };
         // Per front item: four slots in which items change hands (-2: the front roles; 1: stage 2), then the main loop over

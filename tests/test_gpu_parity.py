@@ -430,6 +430,41 @@ def test_comb_walker_fuzz(orc, seed):
         _eq(r[k], want[k], f"seed {seed} w={w} h={h} D={D} cost volumes {k}")
 
 
+@pytest.mark.parametrize("h", [1, 9, 12, 22, 23, 24, 32, 33, 41, 52, 60, 95, 130])
+def test_items_pipelined_across_a_workgroups_tickets(orc, h):
+    """More work items than workgroup slots (3 strips x 2 views x 100 slices = 600 > 512; then 5 strips x 2 x 150 = 1 500): some
+    workgroups take a second and third ticket and start it while stage 2 still finishes the one before (smx_agg_v5.hip,
+    period(h)).  Heights on both sides of where the period is rounded up (h = 12, 32, 52: the last a/b row falls into a band of
+    its own), and images too short for their strip count that must NOT overlap (period < 2 K + 2, smx_agg_v5.h period(): two
+    workgroups can wait for each other's last records -- this test caught that, through the bounded hand-off wait, on
+    h = 9; and with a period of the whole item the completion flag must not wait for the NEXT item's first slots: h = 1, 5 strips).
+    2 strips (300 wide) pipeline from h = 22 with the shortest period there is (6), 3 strips from h = 32, 5 strips from h = 95.
+    Three runs each: the failures were a matter of timing."""
+    for w, D in ((310, 100), (620, 150), (300, 140)):
+        rng = np.random.default_rng(900 + h + w)
+        base = rng.integers(0, 256, size=(h, w + D), dtype=np.uint8)
+        base = (base // 8 * 8).astype(np.uint8)
+        Il = np.ascontiguousarray(base[:, :w])
+        Ir = np.ascontiguousarray(base[:, 7:7 + w])
+        want = orc.stereo_pair(Il, Ir, D)
+        for rep in range(3):
+            r = _device_pair(Il, Ir, D, path=5)
+            for k in KEYS:
+                _eq(r[k], want[k], f"h={h} w={w} run {rep} {k}")
+
+
+def test_items_pipelined_nine_strips(orc):
+    """KITTI's strip count (9) at a height whose period (24 slots) is just above the deadlock-freedom bound 2 K + 2 = 20:
+    720 items on 512 workgroup slots, three runs."""
+    w, h, D = 1242, 200, 40
+    Il, Ir = synth.gen_pair(w, h, D, 77)
+    want = orc.stereo_pair(Il, Ir, D)
+    for rep in range(3):
+        r = _device_pair(Il, Ir, D, path=5)
+        for k in KEYS:
+            _eq(r[k], want[k], f"run {rep} {k}")
+
+
 @pytest.mark.parametrize("radius,w,h", [(0, 128, 52), (0, 129, 53), (4, 64, 26), (4, 65, 78), (4, 192, 27), (4, 64, 16), (9, 130, 33), (1, 70, 48)])
 def test_fused_path_small_radius_at_tile_edges(orc, radius, w, h):
     """Radii other than 9 change the tile width (OW + 2R + 1), the halo width and the row lags."""
