@@ -1576,7 +1576,8 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
                 b.d0[v] = a.v[vv].d0;
             }
             b.w = w; b.h = h; b.K = L.K; b.NI = L.NI;
-            b.P = v5::period(h, L.K);
+            static const int env_no_overlap = env_int_once("SMX_V5_NO_OVERLAP", 0);     // (A/B runs: a period of the whole item)
+            b.P = env_no_overlap ? ((v5::bands(h) + 3) & ~1) : v5::period(h, L.K);
             b.nslices = a.nslices; b.nsv = a.nsv; b.nitems = a.nitems;
             b.hand = (float*)hand; b.flags = a.flags; b.ticket = a.ticket; b.status = a.status;
             b.src_cost = use_cost ? 1 : 0;
