@@ -49,6 +49,34 @@ __device__ __forceinline__ bool div_needs_exact(float x) {
     return !(ax >= 0x1p-100f && ax < __builtin_inff());   // tiny, zero, inf or NaN
 }
 
+// Guidance statistics of one pixel from the integral images S0 (of I) and S1 (of I*I): mean_I = box(S0),
+// var = box(S1) - mean_I*mean_I, 1/(var + eps) in double as the reference's compute_ak_and_bk (guidedFilter.cu:350).
+// Returns (mean_I, 1/(var_I + eps)).
+__device__ __forceinline__ f2 guid_point(const float* __restrict__ S0, const float* __restrict__ S1, int x, int y, int w, int h,
+                                         int R, double eps) {
+    const int ymin = max(-1, y - R - 1), ymax = min(h - 1, y + R);
+    const int xmin = max(-1, x - R - 1), xmax = min(w - 1, x + R);
+    const bool hx = xmin >= 0, hy = ymin >= 0;
+    const size_t i11 = (size_t)ymax * w + xmax, i10 = (size_t)ymax * w + (hx ? xmin : 0);
+    const size_t i01 = (size_t)(hy ? ymin : 0) * w + xmax, i00 = (size_t)(hy ? ymin : 0) * w + (hx ? xmin : 0);
+    const float area = (float)((xmax - xmin) * (ymax - ymin));
+    auto box = [&](const float* __restrict__ S) {      // computeBoxFilterOnGPU guidedFilter.cu:305-318
+        float val = S[i11];
+        if (hx) val -= S[i10];
+        if (hy) val -= S[i01];
+        if (hx && hy) val += S[i00];
+        return 1.0f * val / area;
+    };
+    const float m = box(S0), sq = box(S1);
+    const float m2 = m * m;                             // pixelMultOnGPU(mean, mean) :112
+    const float var = sq - m2;                          // pixelSousOnGPU :121
+    return (f2){m, (float)(1.0f / ((double)var + eps))};
+}
+__device__ __forceinline__ uint8_t mean_to_u8(float m) {   // flToChOnGPU guidedFilter.cu:451-458
+    const int ci = (int)m;
+    return (ci > 255) ? 255 : (uint8_t)ci;
+}
+
 // p = (1-alpha)*min(|I1 - I2|, 7) + alpha*min(|g1 - g2|, 2) and I1*p  (costVolume.cu:187,
 // guidedFilter.cu:209).  The halves convert exactly, so the f32 operations equal the reference's; the
 // sentinel 60000 of an out-of-range partner saturates both terms = the border constant (:184).

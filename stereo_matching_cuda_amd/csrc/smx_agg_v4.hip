@@ -102,7 +102,8 @@ struct Args {
 
 // ---------------------------------------------------------------------------------------------
 // prep: u8 image [h][w] -> (value, x-derivative) half2 plane [h][w + 2 PADX] with PADX sentinel columns on
-// either side.  grid (ceil((w + 2 PADX)/256), h, nimages)      (x_derivativeOnGPU costVolume.cu:358-381)
+// either side (x_derivativeOnGPU costVolume.cu:358-381).  Done by the workgroups of k_v4_guid_rows for their image rows
+// (round 5: a 5 us launch of its own before).
 // ---------------------------------------------------------------------------------------------
 struct PrepArgs {
     const uint8_t* I[2];
@@ -111,23 +112,11 @@ struct PrepArgs {
     unsigned nzero[2];      // saves two fill launches per call
 };
 
-__global__ void k_v4_prep(PrepArgs pa, int w, int h) {
-    if (blockIdx.z == 0) {
-        const unsigned gid = (blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-        const unsigned gsz = gridDim.y * gridDim.x * blockDim.x;
-#pragma unroll
-        for (int r = 0; r < 2; ++r)
-            for (unsigned i = gid; i < pa.nzero[r]; i += gsz) pa.zero[r][i] = 0u;
-    }
-    const uint8_t* __restrict__ I = pa.I[blockIdx.z];
-    fg_t* __restrict__ FG = pa.FG[blockIdx.z];
-    const int xp = blockIdx.x * blockDim.x + threadIdx.x;   // padded column
-    const int y = blockIdx.y;
-    if (xp >= w + 2 * PADX) return;
+// one cell of an image plane: column xp of the padded row (sentinels outside the image)
+__device__ __forceinline__ fg_t prep_cell(const uint8_t* __restrict__ row, int xp, int w) {
     const int x = xp - PADX;
     float f = 60000.0f, g = 60000.0f;
     if (x >= 0 && x < w) {
-        const uint8_t* row = I + (size_t)y * w;
         f = 1.0f * (float)(int)row[x];
         int c1, c2;
         if (x - 1 >= 0 && x + 1 < w) { c1 = row[x + 1]; c2 = row[x - 1]; }
@@ -138,7 +127,7 @@ __global__ void k_v4_prep(PrepArgs pa, int w, int h) {
     fg_t v;
     v.x = (_Float16)f;
     v.y = (_Float16)g;
-    FG[(size_t)y * (w + 2 * PADX) + xp] = v;
+    return v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -151,6 +140,9 @@ struct GuidArgs {
     float* S[2][2];         // [view][plane]: integral of I, integral of I*I (scratch)
     f2* G[2];               // out: (mean_I, 1/(var_I + eps))
     uint8_t* mean_u8[2];    // out, optional: mean_I as u8 (flToChOnGPU guidedFilter.cu:451-458)
+    // k_v4_guid_rows also does k_v4_prep's work (one launch less): the image planes of `nimg` images, the cleared words
+    PrepArgs prep;
+    int nimg, nviews;
 };
 
 // Row prefix sums (rowSum integral.cu:78-90).  One workgroup per `rows` image rows of one view, whole rows in
@@ -164,10 +156,27 @@ __host__ __device__ inline int gr_wpad(int w) { return ((w + 127) & ~127) + 4; }
 __global__ __launch_bounds__(GR_NT) void k_v4_guid_rows(GuidArgs ga, int w, int h, int rows) {
     extern __shared__ __attribute__((aligned(16))) float gr_lds[];
     const int tid = threadIdx.x, view = blockIdx.y, y0 = blockIdx.x * rows;
-    const fg_t* __restrict__ FG = ga.FG[view];
+    const int wp = w + 2 * PADX;
+    // ---- k_v4_prep's part: the padded (value, x-derivative) rows of this workgroup's image rows, the words to clear
+    {
+        const unsigned gid = (blockIdx.y * gridDim.x + blockIdx.x) * GR_NT + tid, gsz = gridDim.y * gridDim.x * GR_NT;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+            for (unsigned i = gid; i < ga.prep.nzero[r]; i += gsz) ga.prep.zero[r][i] = 0u;
+        if (view < ga.nimg) {
+            const uint8_t* __restrict__ I = ga.prep.I[view];
+            fg_t* __restrict__ FGo = ga.prep.FG[view];
+            const int nr = min(rows, h - y0);
+            for (int e = tid; e < nr * wp; e += GR_NT) {
+                const int r = e / wp, xp = e - r * wp;
+                FGo[(size_t)(y0 + r) * wp + xp] = prep_cell(I + (size_t)(y0 + r) * w, xp, w);
+            }
+        }
+        if (view >= ga.nviews) return;          // (an image that is only the other view's partner: no statistics)
+    }
+    const uint8_t* __restrict__ Iu = ga.prep.I[view];
     float* __restrict__ S0 = ga.S[view][0];
     float* __restrict__ S1 = ga.S[view][1];
-    const int wp = w + 2 * PADX;
     const int wpad = gr_wpad(w), wr = wpad - 4;               // wr: a multiple of 128
     float* P0 = gr_lds;
     float* P1 = gr_lds + rows * wpad;
@@ -179,7 +188,7 @@ __global__ __launch_bounds__(GR_NT) void k_v4_guid_rows(GuidArgs ga, int w, int 
         for (int k = 0; k < 16; ++k) {
             const int e = min(e0 + k * GR_NT + tid, total - 1);
             const int r = e / wr, x = e - r * wr;
-            v[k] = (float)FG[(size_t)min(y0 + r, h - 1) * wp + PADX + min(x, w - 1)].x;      // chToFlOnGPU guidedFilter.cu:442-449
+            v[k] = 1.0f * (float)(int)Iu[(size_t)min(y0 + r, h - 1) * w + min(x, w - 1)];     // chToFlOnGPU guidedFilter.cu:442-449
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
@@ -232,28 +241,42 @@ __global__ __launch_bounds__(GR_NT) void k_v4_guid_rows(GuidArgs ga, int w, int 
     }
 }
 
-// Column prefix sums in place (colSum integral.cu:121-131).  One lane per column of one plane; 32 rows of
-// loads in flight.  grid (ceil(w/64), 2 planes, nviews)
-__global__ __launch_bounds__(64) void k_v4_guid_cols(GuidArgs ga, int w, int h) {
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    if (x >= w) return;
-    float* __restrict__ p = ga.S[blockIdx.z][blockIdx.y] + x;
-    float acc = -0.0f;
-    constexpr int NB = 32;
-    float v[NB];
-    int y = 0;
-    for (; y + NB <= h; y += NB) {
+// Column prefix sums in place (colSum integral.cu:121-131): one latency chain of h dependent adds per column.  A workgroup
+// owns 64 columns of one plane; its GC_NW waves take the segments of GC_SEG rows round robin: every wave has the loads of
+// its segment in flight from the start (a wave can track 63 vector-memory operations, and a load takes ~1 us here: one wave per
+// column, round 4, spent 16 us on KITTI shape waiting twelve times for 32 loads queued behind the stores of the batch before),
+// and the chain itself -- the reference's top -> bottom order, one running sum per lane -- is handed from wave to wave
+// through LDS (s_turn: whose segment it is; the waves of a workgroup are co-resident, so the spin cannot starve).
+// grid (ceil(w/64), 2 planes, nviews), block 64 GC_NW
+constexpr int GC_NW = 16, GC_SEG = 32;
+__global__ __launch_bounds__(64 * GC_NW) void k_v4_guid_cols(GuidArgs ga, int w, int h) {
+    __shared__ float s_acc[64];
+    __shared__ int s_turn;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const bool on = x < w;
+    float* __restrict__ p = ga.S[blockIdx.z][blockIdx.y] + min(x, w - 1);
+    if (threadIdx.x == 0) s_turn = 0;
+    __syncthreads();
+    const int nseg = (h + GC_SEG - 1) / GC_SEG;
+    float v[GC_SEG];
+    for (int seg = wv; seg < nseg; seg += GC_NW) {
+        const int y0 = seg * GC_SEG;
 #pragma unroll
-        for (int t = 0; t < NB; ++t) v[t] = p[(size_t)(y + t) * w];
+        for (int t = 0; t < GC_SEG; ++t) v[t] = p[(size_t)min(y0 + t, h - 1) * w];
+        while (__hip_atomic_load(&s_turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != seg) __builtin_amdgcn_s_sleep(1);
+        float acc = seg == 0 ? -0.0f : s_acc[lane];               // -0: the exact additive identity
 #pragma unroll
-        for (int t = 0; t < NB; ++t) {
-            acc = v[t] + acc;
-            p[(size_t)(y + t) * w] = acc;
+        for (int t = 0; t < GC_SEG; ++t) { acc = v[t] + acc; v[t] = acc; }
+        s_acc[lane] = acc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&s_turn, seg + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // (the next wave is on the chain already while this one stores)
+        if (on) {
+#pragma unroll
+            for (int t = 0; t < GC_SEG; ++t)
+                if (y0 + t < h) p[(size_t)(y0 + t) * w] = v[t];
         }
-    }
-    for (; y < h; ++y) {
-        acc = p[(size_t)y * w] + acc;
-        p[(size_t)y * w] = acc;
     }
 }
 
@@ -262,31 +285,10 @@ __global__ __launch_bounds__(64) void k_v4_guid_cols(GuidArgs ga, int w, int h) 
 __global__ void k_v4_guid_finish(GuidArgs ga, int w, int h, int R, double eps) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, view = blockIdx.z;
     if (x >= w) return;
-    const float* __restrict__ S0 = ga.S[view][0];
-    const float* __restrict__ S1 = ga.S[view][1];
-    const int ymin = max(-1, y - R - 1), ymax = min(h - 1, y + R);
-    const int xmin = max(-1, x - R - 1), xmax = min(w - 1, x + R);
-    const bool hx = xmin >= 0, hy = ymin >= 0;
-    const size_t i11 = (size_t)ymax * w + xmax, i10 = (size_t)ymax * w + (hx ? xmin : 0);
-    const size_t i01 = (size_t)(hy ? ymin : 0) * w + xmax, i00 = (size_t)(hy ? ymin : 0) * w + (hx ? xmin : 0);
-    const float area = (float)((xmax - xmin) * (ymax - ymin));
-    auto box = [&](const float* __restrict__ S) {      // computeBoxFilterOnGPU guidedFilter.cu:305-318
-        float val = S[i11];
-        if (hx) val -= S[i10];
-        if (hy) val -= S[i01];
-        if (hx && hy) val += S[i00];
-        return 1.0f * val / area;
-    };
-    const float m = box(S0), s = box(S1);
-    const float m2 = m * m;                             // pixelMultOnGPU(mean, mean) :112
-    const float var = s - m2;                           // pixelSousOnGPU :121
-    const float c = (float)(1.0f / ((double)var + eps));
+    const f2 g = guid_point(ga.S[view][0], ga.S[view][1], x, y, w, h, R, eps);
     const size_t id = (size_t)y * w + x;
-    ga.G[view][id] = (f2){m, c};
-    if (ga.mean_u8[view]) {
-        const int ci = (int)m;
-        ga.mean_u8[view][id] = (ci > 255) ? 255 : (uint8_t)ci;
-    }
+    ga.G[view][id] = g;
+    if (ga.mean_u8[view]) ga.mean_u8[view][id] = mean_to_u8(g.x);
 }
 
 // Hand-off record of one iteration (per parity and slice-view), written and read in 16-byte units:
@@ -1494,9 +1496,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     const int nimg = pa.I[1] ? 2 : 1;
     pa.zero[0] = status; pa.nzero[0] = 64;
     pa.zero[1] = (unsigned*)ctrl; pa.nzero[1] = (unsigned)(v4_flag_bytes_k(K_c, nsv_max) / 4);
-    hipLaunchKernelGGL(v4::k_v4_prep, dim3(cdivu4(w + 2 * v4::PADX, 256), h, nimg), dim3(256), 0, st, pa, w, h);
-    SMX_HIP(hipGetLastError());
-    ++nl;
+    // (no launch of its own: k_v4_guid_rows below does this kernel's work for its image rows)
 
     // ---- guidance statistics (guidedFilter.cu:58-123): (mean_I, 1/(var_I + eps)), optional u8 mean image
     {
@@ -1508,6 +1508,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             ga.G[v] = gpair[v];
             ga.mean_u8[v] = d_mean_u8 ? d_mean_u8[v] : nullptr;
         }
+        ga.prep = pa; ga.nimg = nimg; ga.nviews = nviews;
         {
             // rows per workgroup: few enough that the launch fills the chip, and whole rows fit the LDS
             const int wpad = v4::gr_wpad(w);
@@ -1519,17 +1520,21 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
             if (rows < 1) return fail(SMX_E_ARG, "aggregate_v4: image too wide for the guidance row scan");
             static LdsLimitOnce lim;     // (once per device: the sharded driver runs several devices from one process)
             SMX_HIP(lim.ensure((const void*)v4::k_v4_guid_rows, 160 * 1024));
-            hipLaunchKernelGGL(v4::k_v4_guid_rows, dim3(cdivu4(h, rows), nviews), dim3(v4::GR_NT), (size_t)8 * rows * wpad, st,
+            hipLaunchKernelGGL(v4::k_v4_guid_rows, dim3(cdivu4(h, rows), nimg > nviews ? nimg : nviews), dim3(v4::GR_NT), (size_t)8 * rows * wpad, st,
                                ga, w, h, rows);
         }
-        hipLaunchKernelGGL(v4::k_v4_guid_cols, dim3(cdivu4(w, 64), 2, nviews), dim3(64), 0, st, ga, w, h);
-        hipLaunchKernelGGL(v4::k_v4_guid_finish, dim3(cdivu4(w, 256), h, nviews), dim3(256), 0, st, ga, w, h, R, p->eps);
+        hipLaunchKernelGGL(v4::k_v4_guid_cols, dim3(cdivu4(w, 64), 2, nviews), dim3(64 * v4::GC_NW), 0, st, ga, w, h);
+        if (use_v5) {
+            // (the comb walker's planes: the statistics are evaluated where the comb-ordered copy is written, and G / the u8
+            // mean leave from there too -- one launch and one round trip of G less than finish + permute)
+            const float* S0[2] = {ga.S[0][0], ga.S[1][0]};
+            const float* S1[2] = {ga.S[0][1], ga.S[1][1]};
+            if ((rc = v5_perm_launch(nviews, S0, S1, gpair, ga.mean_u8, FG, g1p, i2p, w, h, p->eps, st))) return rc;
+        } else {
+            hipLaunchKernelGGL(v4::k_v4_guid_finish, dim3(cdivu4(w, 256), h, nviews), dim3(256), 0, st, ga, w, h, R, p->eps);
+        }
         SMX_HIP(hipGetLastError());
         nl += 3;
-        if (use_v5) {
-            if ((rc = v5_perm_launch(nviews, gpair, FG, g1p, i2p, w, h, st))) return rc;
-            ++nl;
-        }
     }
     stage_mark(ST_GUIDANCE, st);
 
@@ -1561,7 +1566,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
         a.hand = hand;
         a.ticket = (unsigned*)ctrl; a.status = status;
         a.flags = (unsigned*)(ctrl + V4_CTRL_BYTES);
-        if (s0 != s_begin) SMX_HIP(hipMemsetAsync(ctrl, 0, v4_flag_bytes_k(K_c, a.nsv), st));   // (first chunk: cleared by k_v4_prep)
+        if (s0 != s_begin) SMX_HIP(hipMemsetAsync(ctrl, 0, v4_flag_bytes_k(K_c, a.nsv), st));   // (first chunk: cleared by k_v4_guid_rows)
         if (use_v5) {
             v5::Args b;
             memset(&b, 0, sizeof(b));

@@ -70,7 +70,7 @@ inline int period(int h, int K) {
     // (2 slots of lag per strip, at most K - 2 of them) reaches slot 2 K - 5 < p - 4 at most, so between two late waits a
     // cycle passes a workgroup that has not even STARTED the awaited item; (2) tickets are taken in slot p - 6 >= 0, behind a
     // flag wait, so a left neighbour's workgroup takes its next ticket before the right neighbour's does.  With both, the
-    // largest ticket among the items of a cycle cannot be reached again by walking the cycle.  (h = 9, p = 4: two workgroups
+    // ticket of the item a workgroup has just started falls strictly from one late wait of a cycle to the next: there is no cycle.  (h = 9, p = 4: two workgroups
     // waited for each other's last records; caught by the bounded wait,
     // tests/test_gpu_parity.py::test_items_pipelined_across_a_workgroups_tickets.)  Short or wide-and-short images get a
     // period of the whole item: nothing overlaps, an item's completion is published before its workgroup waits for anything
@@ -89,8 +89,9 @@ bool v5_supported(const smx_params* p);
 bool v5_supported_cost(const smx_params* p);     // the same for materialised cost volumes (values checked in the kernel)
 int v5_launch(const v5::Args& a, hipStream_t st);
 // comb-ordered guidance planes of one call: G (mean_I, 1/(var+eps)) [h][w] and the image planes FG -> g1p, i2p
-int v5_perm_launch(int nviews, const aggdev::f2* const* G, const aggdev::fg_t* const* FG, aggdev::f2* const* g1p,
-                   unsigned* const* i2p, int w, int h, hipStream_t st);
+int v5_perm_launch(int nviews, const float* const* S0, const float* const* S1, aggdev::f2* const* G, uint8_t* const* mean_u8,
+                   const aggdev::fg_t* const* FG, aggdev::f2* const* g1p, unsigned* const* i2p, int w, int h, double eps,
+                   hipStream_t st);
 // packed-key WTA over `count` comb-ordered q planes (slice slice0 ..) of `nviews` views -> keys [h][w]
 // (skip_if != NULL: a device word; the pass does nothing when it is nonzero)
 int v5_wta_launch(int nviews, const float* const* q, int64_t* const* keys, int w, int h, int count, int slice0,

@@ -1200,10 +1200,14 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// comb-ordered guidance planes: grid (K * h, nviews), block CLP
+// guidance statistics (guidedFilter.cu:58-123, from the integral images) + their comb-ordered copies: grid (K * NI * 5, nviews), block CLP
 // ---------------------------------------------------------------------------------------------------------------
 struct PermArgs {
-    const f2* G[2];
+    const float* S0[2];     // integral images of I and I*I (k_v4_guid_rows / k_v4_guid_cols)
+    const float* S1[2];
+    f2* G[2];               // out: (mean_I, 1/(var_I + eps)) [h][w] (the ring walker's layout; the caller's mean image comes from it)
+    uint8_t* mean_u8[2];    // out, optional
+    double eps;
     const fg_t* FG[2];
     f2* g1p[2];
     unsigned* i2p[2];
@@ -1211,40 +1215,46 @@ struct PermArgs {
 __global__ __launch_bounds__(CLP) void k_v5_perm(PermArgs pa, int w, int h, int K, int NI) {
     const int cl = threadIdx.x, cw = cl >> 6, ln = cl & 63;
     const int rho = ln / L < CPW ? CPW * cw + ln / L : HW, il = ln % L;
-    const int k = blockIdx.x / NI, ib = blockIdx.x - k * NI, v = blockIdx.y;
+    const int kb = blockIdx.x / (BH / 2), j = blockIdx.x - kb * (BH / 2);   // one row pair of a band per workgroup
+    const int k = kb / NI, ib = kb - k * NI, v = blockIdx.y;
     const int x1 = OWS * k - R - 1 + HW * il + rho;     // a/b column of stage-1 comb lane cl
     const int xq = x1 - R;                              // q column of stage-2 comb lane cl
     const bool on1 = rho < HW && x1 >= 0 && x1 < w, on2 = rho < HW && xq >= 0 && xq < w;
-    // stage 1: the a/b rows 10 ib - 9 + t of band ib as five row pairs (rows clamped into the image; the a_k, b_k of rows
-    // outside it are replaced by -0 whatever their guidance)
-    f4* const g1 = (f4*)pa.g1p[v];
-#pragma unroll
-    for (int j = 0; j < BH / 2; ++j) {
+    // stage 1: the a/b rows 10 ib - 9 + 2 j, + 1 of band ib (rows clamped into the image; the a_k, b_k of rows outside it are
+    // replaced by -0 whatever their guidance)
+    {
         const int ya = min(max(BH * ib - R + 2 * j, 0), h - 1), yb = min(max(BH * ib - R + 2 * j + 1, 0), h - 1);
         f4 g = {0.0f, 0.0f, 0.0f, 0.0f};
         if (on1) {
-            const f2 a = pa.G[v][(size_t)ya * w + x1], b = pa.G[v][(size_t)yb * w + x1];
+            // (a pixel is evaluated by every strip whose a/b columns hold it and once more per clamped row: 1.13 evaluations
+            // per pixel on KITTI shape, all with the same result -- whichever store lands last, G holds that value)
+            const f2 a = guid_point(pa.S0[v], pa.S1[v], x1, ya, w, h, R, pa.eps);
+            const f2 b = yb == ya ? a : guid_point(pa.S0[v], pa.S1[v], x1, yb, w, h, R, pa.eps);
             g = (f4){a.x, a.y, b.x, b.y};
+            pa.G[v][(size_t)ya * w + x1] = a;
+            pa.G[v][(size_t)yb * w + x1] = b;
+            if (pa.mean_u8[v]) {
+                pa.mean_u8[v][(size_t)ya * w + x1] = mean_to_u8(a.x);
+                pa.mean_u8[v][(size_t)yb * w + x1] = mean_to_u8(b.x);
+            }
         }
-        g1[((size_t)k * (5 * NI) + 5 * ib + j) * CLP + cl] = g;
+        ((f4*)pa.g1p[v])[((size_t)k * (5 * NI) + 5 * ib + j) * CLP + cl] = g;
     }
-    // stage 2: the q rows 10 (ib - 1) - 18 + 2 m, + 1 of band ib: image values as fp16 pairs (row pairs clamped like the
-    // loads they replace; a row behind the image holds 0)
-    unsigned pr[BH / 2];
-#pragma unroll
-    for (int m = 0; m < BH / 2; ++m) {
-        const int yp = min(max((BH * (ib - 1) - 2 * R) / 2 + m, 0), (h - 1) / 2), y = 2 * yp;
+    // stage 2: the q rows 10 (ib - 1) - 18 + 2 j, + 1 of band ib: image values as an fp16 pair (row pairs clamped like the
+    // loads they replace; a row behind the image holds 0); pairs 0 .. 3 of a band form a u32x4, pair 4 lies behind them
+    {
+        const int yp = min(max((BH * (ib - 1) - 2 * R) / 2 + j, 0), (h - 1) / 2), y = 2 * yp;
         fg_t p2 = {(_Float16)0.0f, (_Float16)0.0f};
         if (on2) {
             p2.x = pa.FG[v][(size_t)y * (w + 2 * PADX) + PADX + xq].x;
             if (y + 1 < h) p2.y = pa.FG[v][(size_t)(y + 1) * (w + 2 * PADX) + PADX + xq].x;
         }
-        pr[m] = __builtin_bit_cast(unsigned, p2);
+        const unsigned pr = __builtin_bit_cast(unsigned, p2);
+        unsigned* const i2a = pa.i2p[v];
+        unsigned* const i2b = pa.i2p[v] + (size_t)K * NI * CLP * 4;
+        const size_t e = ((size_t)k * NI + ib) * CLP + cl;
+        if (j < 4) i2a[4 * e + j] = pr; else i2b[e] = pr;
     }
-    u4* const i2a = (u4*)pa.i2p[v];
-    unsigned* const i2b = pa.i2p[v] + (size_t)K * NI * CLP * 4;
-    i2a[((size_t)k * NI + ib) * CLP + cl] = (u4){pr[0], pr[1], pr[2], pr[3]};
-    i2b[((size_t)k * NI + ib) * CLP + cl] = pr[4];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1316,13 +1326,18 @@ __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K
 
 }  // namespace v5
 
-int v5_perm_launch(int nviews, const aggdev::f2* const* G, const aggdev::fg_t* const* FG, aggdev::f2* const* g1p,
-                   unsigned* const* i2p, int w, int h, hipStream_t st) {
+int v5_perm_launch(int nviews, const float* const* S0, const float* const* S1, aggdev::f2* const* G, uint8_t* const* mean_u8,
+                   const aggdev::fg_t* const* FG, aggdev::f2* const* g1p, unsigned* const* i2p, int w, int h, double eps,
+                   hipStream_t st) {
     v5::PermArgs pa;
     memset(&pa, 0, sizeof(pa));
-    for (int v = 0; v < nviews; ++v) { pa.G[v] = G[v]; pa.FG[v] = FG[v]; pa.g1p[v] = g1p[v]; pa.i2p[v] = i2p[v]; }
+    for (int v = 0; v < nviews; ++v) {
+        pa.S0[v] = S0[v]; pa.S1[v] = S1[v]; pa.G[v] = G[v]; pa.mean_u8[v] = mean_u8[v];
+        pa.FG[v] = FG[v]; pa.g1p[v] = g1p[v]; pa.i2p[v] = i2p[v];
+    }
+    pa.eps = eps;
     const int K = v5::strips(w), NI = v5::bands(h);
-    hipLaunchKernelGGL(v5::k_v5_perm, dim3((unsigned)(K * NI), (unsigned)nviews), dim3(v5::CLP), 0, st, pa, w, h, K, NI);
+    hipLaunchKernelGGL(v5::k_v5_perm, dim3((unsigned)(K * NI * (v5::BH / 2)), (unsigned)nviews), dim3(v5::CLP), 0, st, pa, w, h, K, NI);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
