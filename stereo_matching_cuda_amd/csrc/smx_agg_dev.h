@@ -96,7 +96,10 @@ __device__ __forceinline__ f2 cost_pair(fg_t q1, fg_t q2, const CostConst& cc) {
 // ---- hand-off accesses: sc1 (bypass this CU's L1, write through the XCD's L2) ----------------
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 constexpr int AUX_SC1 = 16;
-constexpr int AUX_NT = 2;   // q stores and the WTA's q loads are nt: measured best of plain / sc1 / nt
+#ifndef SMX_Q_ST_AUX
+#define SMX_Q_ST_AUX 2     // (A/B: 0 plain, 2 nt)
+#endif
+constexpr int AUX_NT = SMX_Q_ST_AUX;   // q stores and the WTA's q loads are nt: measured best of plain / sc1 / nt
 __device__ __forceinline__ rsrc_t mk_rsrc(const void* p, size_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0,
                                              (int)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes),

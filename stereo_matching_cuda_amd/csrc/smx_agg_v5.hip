@@ -1274,7 +1274,11 @@ static_assert(OWS % 4 == 0, "quads do not straddle strip rows");
 __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K, int count, int slice0) {
     constexpr int EPL = 4;
     const size_t np = (size_t)K * h * OWS;
+#ifdef SMX_WTA_REV       // (A/B: the planes back to front -- the strips the walker wrote last first)
+    const size_t e0 = ((size_t)(gridDim.x - 1 - blockIdx.x) * 256 + threadIdx.x) * EPL;
+#else
     const size_t e0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * EPL;
+#endif
     if (e0 >= np || (wa.skip_if && flag_load(const_cast<unsigned*>(wa.skip_if)) != 0u)) return;
     const float* __restrict__ q = wa.q[blockIdx.y] + e0;
     int64_t* const keys = wa.keys[blockIdx.y];
@@ -1302,7 +1306,11 @@ __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K
     for (; z + U <= count; z += U) {
         fv v[U];
 #pragma unroll
+#ifdef SMX_WTA_LD_PLAIN
+        for (int t = 0; t < U; ++t) v[t] = *(const fv*)&q[(size_t)(z + t) * np];
+#else
         for (int t = 0; t < U; ++t) v[t] = __builtin_nontemporal_load((const fv*)&q[(size_t)(z + t) * np]);
+#endif
 #pragma unroll
         for (int t = 0; t < U; ++t)
 #pragma unroll
