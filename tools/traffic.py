@@ -12,7 +12,7 @@ import collections
 import csv
 import glob
 import json
-import sys
+import os, sys
 
 AGG_KERNELS = ("k_v4_", "k_v5_")      # every kernel of the fused aggregation call (either walker)
 WALKERS = ("k_v5_walk", "k_v4_walk")
@@ -37,7 +37,7 @@ def main(src, dst=None):
     agg = [k for k in per if any(a in k for a in AGG_KERNELS)]
     walk = [k for k in per if any(a in k for a in WALKERS)]
     try:
-        sys.path.insert(0, ".")
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # (the GPU scripts run this from /tmp)
         import stereo_matching_cuda_amd as smx
         library = smx.lib().smx_version().decode()
     except Exception:                                   # noqa: BLE001 (dev tool: the tag is best effort)
