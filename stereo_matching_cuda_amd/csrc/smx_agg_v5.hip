@@ -147,6 +147,9 @@ constexpr int WMAP = SMX_V5_WMAP;
 constexpr int S2_KEEP = SMX_V5_S2_KEEP;     // vector-memory operations a stage-2 wave issues behind its record store in an interior slot
 constexpr int PRIO_COST = SMX_V5_PRIO_COST, PRIO_S1 = SMX_V5_PRIO_S1, PRIO_S2HEAD = SMX_V5_PRIO_S2HEAD, PRIO_SCAN = SMX_V5_PRIO_SCAN;
 
+#if (SMX_V5_WHATIF & 16384)
+__device__ uint64_t g_masksink[1 << 16];
+#endif
 #ifdef SMX_V5_DUMP
 // Diagnostic build only: tile 1 (current buffer), tile 2 and the comb registers of one item behind the barrier that
 // ends phase SMX_V5_DUMP_PH (0 W, 1 R, 2 X) of iteration SMX_V5_DUMP_IT
@@ -311,6 +314,13 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
         unsigned* myflag = A.flags;
         int o_fg1 = 0, o_fg2 = 0, o_g1p = 0, o_i2p = 0, o_i2b = 0, o_in = 0, o_out = 0;
         rsrc_t r_q = r_fix;
+#if (SMX_V5_WHATIF & 16384)
+        // (what-if 16384: the cost of a pairwise pre-reduction of q in stage 2 -- odd slices load the q rows of the slice before,
+        // select, store the minimum and a ballot; results wrong by construction)
+        [[maybe_unused]] float qo[(ST2 && (WHATIF & 16384)) ? BH : 1];
+        [[maybe_unused]] rsrc_t r_qp = r_fix;
+        [[maybe_unused]] bool pairB = false;
+#endif
         // q rows: comb-ordered scratch (row y of this strip at (k h + y) * OWS) or the caller's [h][w]
         int q_pitch = 0, q_row0 = 0;
         auto decode = [&](int it) {
@@ -333,6 +343,10 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             o_in = (int)((((unsigned)(k - 1) & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
             o_out = (int)((((unsigned)k & 1u) * (unsigned)nsv + (unsigned)sv) * recb);
             r_q = mk_rsrc(A.q[view] + (size_t)slice * A.q_plane, A.q_plane * 4);
+#if (SMX_V5_WHATIF & 16384)
+            pairB = (slice & 1) != 0;
+            r_qp = mk_rsrc(A.q[view] + (size_t)(slice > 0 ? slice - 1 : 0) * A.q_plane, A.q_plane * 4);
+#endif
             q_pitch = A.qperm ? OWS * 4 : (int)w4; q_row0 = A.qperm ? k * h * (OWS * 4) : 0;
             xedge = base1 < 0 || base1 + SW > w;
         };
@@ -860,8 +874,23 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             const fg_t ip = __builtin_bit_cast(fg_t, gI[T0 / 2]);
             const float tqa = ma.x * (float)ip.x;      // compute_q guidedFilter.cu:363-369
             const float tqb = mb.x * (float)ip.y;
-            const float qva = tqa + ma.y;
-            const float qvb = tqb + mb.y;
+            float qva = tqa + ma.y;
+            float qvb = tqb + mb.y;
+#if (SMX_V5_WHATIF & 16384)
+            if constexpr (ST2) {
+                if (pairB) {
+                    const float oa = qo[T0], ob = qo[T0 + 1];
+                    const bool sa = qva == qva && !(oa < qva), sb = qvb == qvb && !(ob < qvb);
+                    const uint64_t ba = __builtin_amdgcn_ballot_w64(sa), bb = __builtin_amdgcn_ballot_w64(sb);
+                    qva = sa ? qva : oa;
+                    qvb = sb ? qvb : ob;
+                    if (lane == 0) {
+                        g_masksink[((blockIdx.x * 8 + wave) * 64 + (yq & 31)) & 0xffff] = ba;
+                        g_masksink[((blockIdx.x * 8 + wave) * 64 + 32 + (yq & 31)) & 0xffff] = bb;
+                    }
+                }
+            }
+#endif
             if (!(WHATIF & 16)) {
                 if (va) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qva), r_q, (int)vo, q_row0 + yq * q_pitch, AUX_NT);
                 if (vb) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qvb), r_q, (int)vo, q_row0 + (yq + 1) * q_pitch, AUX_NT);
@@ -1010,6 +1039,15 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                     const int yq0 = BH * (sl - 2) - 2 * R;
                     const bool border = yq0 < R + 1 || yq0 + BH - 1 > h - 1 - R;
                     s2_interior = !border && !(WHATIF & (8 | 16 | 32)) && sl != q_last;
+#if (SMX_V5_WHATIF & 16384)
+                    if constexpr (ST2) {
+                        if (pairB) {
+#pragma unroll
+                            for (int t = 0; t < BH; ++t)
+                                qo[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_qp, (int)vo, q_row0 + min(max(yq0 + t, 0), h - 1) * q_pitch, AUX_NT));
+                        }
+                    }
+#endif
                     __builtin_amdgcn_sched_barrier(0);
                     if (!(WHATIF & 8)) {
 #define V5_P2(TT) rows2_pair(std::integral_constant<int, BH * PAR + TT>{}, std::false_type{}, sl);
@@ -1367,6 +1405,7 @@ int v5_wta_launch(int nviews, const float* const* q, int64_t* const* keys, int w
 }
 
 void v5_geometry(int* ow, int* bh) { *ow = v5::OWS; *bh = v5::BH; }
+void v5_slots(int h, int K, int* bands, int* q_last, int* period) { *bands = v5::bands(h); *q_last = (h + 37) / 10; *period = v5::period(h, K); }
 
 bool v5_supported(const smx_params* p) {
     if (p->radius != v5::R) return false;

@@ -64,6 +64,7 @@ void v4_geometry(int* ow, int* bh);
 // smx_agg_v5.hip
 bool v5_supported(const smx_params* p);
 void v5_geometry(int* ow, int* bh);
+void v5_slots(int h, int K, int* bands, int* q_last, int* period);
 
 // the fused aggregation; reports the path that ran: 2 = ring walker, 4 = FAST, 5 = comb walker
 static int aggregate_fused(int path, const smx_params* p, int nviews, const uint8_t* const* d_guide,
@@ -259,6 +260,18 @@ int smx_last_agg_chunk(int* slices_per_launch, int* walker_launches) {
 __attribute__((visibility("default"))) int smx_debug_v5_fix_bytes(int w, int h, int nviews, uint64_t* bytes) {
     SMX_ARG(bytes && w >= 2 && h >= 1 && (nviews == 1 || nviews == 2));
     *bytes = (uint64_t)v5_fix_bytes(w, h, nviews);
+    return SMX_OK;
+}
+
+// (dev / test hook, not in smx.h: the comb walker's slot geometry for an image of h rows in K strips -- bands per item, the
+// last stage-2 slot, the period between the starts of two items of a workgroup -- for tools/v5_protocol_sim.py)
+__attribute__((visibility("default"))) int smx_debug_v5_period(int h, int K, int* bands, int* q_last, int* period) {
+    SMX_ARG(h >= 1 && K >= 1);
+    int b = 0, q = 0, pd = 0;
+    v5_slots(h, K, &b, &q, &pd);
+    if (bands) *bands = b;
+    if (q_last) *q_last = q;
+    if (period) *period = pd;
     return SMX_OK;
 }
 
