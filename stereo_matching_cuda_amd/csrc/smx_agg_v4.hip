@@ -112,24 +112,6 @@ struct PrepArgs {
     unsigned nzero[2];      // saves two fill launches per call
 };
 
-// one cell of an image plane: column xp of the padded row (sentinels outside the image)
-__device__ __forceinline__ fg_t prep_cell(const uint8_t* __restrict__ row, int xp, int w) {
-    const int x = xp - PADX;
-    float f = 60000.0f, g = 60000.0f;
-    if (x >= 0 && x < w) {
-        f = 1.0f * (float)(int)row[x];
-        int c1, c2;
-        if (x - 1 >= 0 && x + 1 < w) { c1 = row[x + 1]; c2 = row[x - 1]; }
-        else if (x + 1 >= w)         { c1 = row[x];     c2 = row[x - 1]; }
-        else                         { c1 = row[x + 1]; c2 = row[x];     }
-        g = 1.0f * (float)(c2 - c1) / 2;
-    }
-    fg_t v;
-    v.x = (_Float16)f;
-    v.y = (_Float16)g;
-    return v;
-}
-
 // ---------------------------------------------------------------------------------------------
 // guidance statistics (guidedFilter.cu:58-123): integral images of I and I*I (integral.cu:78-131, the
 // reference's sequential row prefix then sequential column prefix), box means, variance, 1/(var + eps).
@@ -157,22 +139,12 @@ __global__ __launch_bounds__(GR_NT) void k_v4_guid_rows(GuidArgs ga, int w, int 
     extern __shared__ __attribute__((aligned(16))) float gr_lds[];
     const int tid = threadIdx.x, view = blockIdx.y, y0 = blockIdx.x * rows;
     const int wp = w + 2 * PADX;
-    // ---- k_v4_prep's part: the padded (value, x-derivative) rows of this workgroup's image rows, the words to clear
+    // ---- k_v4_prep's part I: the words to clear
     {
         const unsigned gid = (blockIdx.y * gridDim.x + blockIdx.x) * GR_NT + tid, gsz = gridDim.y * gridDim.x * GR_NT;
 #pragma unroll
         for (int r = 0; r < 2; ++r)
             for (unsigned i = gid; i < ga.prep.nzero[r]; i += gsz) ga.prep.zero[r][i] = 0u;
-        if (view < ga.nimg) {
-            const uint8_t* __restrict__ I = ga.prep.I[view];
-            fg_t* __restrict__ FGo = ga.prep.FG[view];
-            const int nr = min(rows, h - y0);
-            for (int e = tid; e < nr * wp; e += GR_NT) {
-                const int r = e / wp, xp = e - r * wp;
-                FGo[(size_t)(y0 + r) * wp + xp] = prep_cell(I + (size_t)(y0 + r) * w, xp, w);
-            }
-        }
-        if (view >= ga.nviews) return;          // (an image that is only the other view's partner: no statistics)
     }
     const uint8_t* __restrict__ Iu = ga.prep.I[view];
     float* __restrict__ S0 = ga.S[view][0];
@@ -201,6 +173,29 @@ __global__ __launch_bounds__(GR_NT) void k_v4_guid_rows(GuidArgs ga, int w, int 
         }
     }
     __syncthreads();
+    // ---- k_v4_prep's part II: the padded (value, x-derivative) rows out of the pixel values in LDS (x_derivativeOnGPU
+    // costVolume.cu:358-381: (I[x-1] - I[x+1]) / 2, one-sided at the image edges; integers <= 255: exact whichever way formed).
+    // (From global memory, a cell per loop trip, this part cost 5 us: its byte loads were waited for trip by trip.)
+    if (view < ga.nimg) {
+        fg_t* __restrict__ FGo = ga.prep.FG[view];
+        const int nr = min(rows, h - y0);
+        for (int e = tid; e < nr * wp; e += GR_NT) {
+            const int r = e / wp, xp = e - r * wp, x = xp - PADX;
+            float f = 60000.0f, g = 60000.0f;
+            if (x >= 0 && x < w) {
+                const float* pr = P0 + r * wpad;
+                f = pr[x];
+                const float c1 = pr[x + 1 < w ? x + 1 : x], c2 = pr[x - 1 >= 0 ? x - 1 : x];     // (w >= 2)
+                g = 1.0f * (c2 - c1) / 2;
+            }
+            fg_t v;
+            v.x = (_Float16)f;
+            v.y = (_Float16)g;
+            FGo[(size_t)(y0 + r) * wp + xp] = v;
+        }
+    }
+    if (view >= ga.nviews) return;          // (an image that is only the other view's partner: no statistics)
+    __syncthreads();                        // (the scan below overwrites the pixel values in place)
     // (2) columns behind the image hold copies of the last pixel; their sums are never stored
     if (tid < 2 * rows) {
         float* row = gr_lds + tid * wpad;                     // tid = plane * rows + row
