@@ -290,6 +290,8 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
     // item.  One global slot counter g per wave; the front item's local slot is slf = g - P n - 2.  Tile buffers are indexed by
     // GLOBAL band (local band + P n = `boff`), so the front item's band b and the back item's band b + P share a buffer exactly
     // as two bands of one item do, and the same protocols (slot barrier, x1 counter) order their uses.
+    // (Short or wide-and-short images get a period of the whole item, NI + 2: smx_agg_v5.h period() and DESIGN.md 4.1 -- the
+    // argument why no cycle of flag waits exists; tools/v5_protocol_sim.py is this protocol as a CPU model.)
     if (tid == 0) {
         s_queue[0] = (int)__hip_atomic_fetch_add((gu32*)A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_x1 = 0u; s_peek[0] = 0u; s_peek[1] = 0u; s_peekn = 0u;
