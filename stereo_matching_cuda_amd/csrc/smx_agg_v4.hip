@@ -135,6 +135,9 @@ struct GuidArgs {
 constexpr int GR_NT = 256;
 constexpr int GR_MAXROWS = 8;
 __host__ __device__ inline int gr_wpad(int w) { return ((w + 127) & ~127) + 4; }
+#ifndef SMX_GR_WHATIF
+#define SMX_GR_WHATIF 0     // diagnostic builds (WRONG results): 1 no scan, 2 no S stores, 4 no image planes, 8 no pixel loads
+#endif
 __global__ __launch_bounds__(GR_NT) void k_v4_guid_rows(GuidArgs ga, int w, int h, int rows) {
     extern __shared__ __attribute__((aligned(16))) float gr_lds[];
     const int tid = threadIdx.x, view = blockIdx.y, y0 = blockIdx.x * rows;
@@ -160,6 +163,7 @@ __global__ __launch_bounds__(GR_NT) void k_v4_guid_rows(GuidArgs ga, int w, int 
         for (int k = 0; k < 16; ++k) {
             const int e = min(e0 + k * GR_NT + tid, total - 1);
             const int r = e / wr, x = e - r * wr;
+            if (SMX_GR_WHATIF & 8) v[k] = (float)(e & 255); else
             v[k] = 1.0f * (float)(int)Iu[(size_t)min(y0 + r, h - 1) * w + min(x, w - 1)];     // chToFlOnGPU guidedFilter.cu:442-449
         }
 #pragma unroll
@@ -176,7 +180,7 @@ __global__ __launch_bounds__(GR_NT) void k_v4_guid_rows(GuidArgs ga, int w, int 
     // ---- k_v4_prep's part II: the padded (value, x-derivative) rows out of the pixel values in LDS (x_derivativeOnGPU
     // costVolume.cu:358-381: (I[x-1] - I[x+1]) / 2, one-sided at the image edges; integers <= 255: exact whichever way formed).
     // (From global memory, a cell per loop trip, this part cost 5 us: its byte loads were waited for trip by trip.)
-    if (view < ga.nimg) {
+    if (view < ga.nimg && !(SMX_GR_WHATIF & 4)) {
         fg_t* __restrict__ FGo = ga.prep.FG[view];
         const int nr = min(rows, h - y0);
         for (int e = tid; e < nr * wp; e += GR_NT) {
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(GR_NT) void k_v4_guid_rows(GuidArgs ga, int w, int 
     if (view >= ga.nviews) return;          // (an image that is only the other view's partner: no statistics)
     __syncthreads();                        // (the scan below overwrites the pixel values in place)
     // (2) columns behind the image hold copies of the last pixel; their sums are never stored
-    if (tid < 2 * rows) {
+    if (tid < 2 * rows && !(SMX_GR_WHATIF & 1)) {
         float* row = gr_lds + tid * wpad;                     // tid = plane * rows + row
         float acc = -0.0f;                                    // exact additive identity
         f4 c[16], n[16];
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(GR_NT) void k_v4_guid_rows(GuidArgs ga, int w, int 
     }
     __syncthreads();
     for (int r = 0; r < rows; ++r) {
-        if (y0 + r >= h) break;
+        if (y0 + r >= h || (SMX_GR_WHATIF & 2)) break;
         float* d0 = S0 + (size_t)(y0 + r) * w;
         float* d1 = S1 + (size_t)(y0 + r) * w;
         for (int x = tid; x < w; x += GR_NT) {
