@@ -1229,23 +1229,19 @@ __global__ __launch_bounds__(256) void k_v4_wta(WtaArgs wa, size_t n, int count,
     if (id >= n || wta_gate_closed(wa.gate, wa.gate_nonzero)) return;
     const float* __restrict__ q = wa.q[blockIdx.y] + id;
     int64_t* keys = wa.keys[blockIdx.y];
-    int64_t key = wa.fresh ? KEY_IDENTITY : keys[id];
+    const int64_t key = wa.fresh ? KEY_IDENTITY : keys[id];
+    WtaRun r;                           // (smx_common.h: the winner of this call's slices, packed once)
     int z = 0;
     for (; z + 8 <= count; z += 8) {
         float v[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) v[t] = __builtin_nontemporal_load(&q[(size_t)(z + t) * n]);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            int64_t kk = pack_key(v[t], (uint32_t)(slice0 + z + t));
-            key = kk < key ? kk : key;
-        }
+        for (int t = 0; t < 8; ++t) r.step(v[t], (uint32_t)(slice0 + z + t));
     }
-    for (; z < count; ++z) {
-        int64_t kk = pack_key(__builtin_nontemporal_load(&q[(size_t)z * n]), (uint32_t)(slice0 + z));
-        key = kk < key ? kk : key;
-    }
-    keys[id] = key;
+    for (; z < count; ++z) r.step(__builtin_nontemporal_load(&q[(size_t)z * n]), (uint32_t)(slice0 + z));
+    const int64_t kk = r.key();
+    keys[id] = kk < key ? kk : key;
 }
 
 // The same with two pixels per lane (8-byte loads).  Needs an even plane size n and 8-byte aligned planes.
@@ -1255,28 +1251,28 @@ __global__ __launch_bounds__(256) void k_v4_wta2(WtaArgs wa, size_t n, int count
     if (id >= n || wta_gate_closed(wa.gate, wa.gate_nonzero)) return;
     const float* __restrict__ q = wa.q[blockIdx.y] + id;
     int64_t* keys = wa.keys[blockIdx.y];
-    int64_t k0 = wa.fresh ? KEY_IDENTITY : keys[id], k1 = wa.fresh ? KEY_IDENTITY : keys[id + 1];
+    const int64_t k0 = wa.fresh ? KEY_IDENTITY : keys[id], k1 = wa.fresh ? KEY_IDENTITY : keys[id + 1];
+    WtaRun r0, r1;
     int z = 0;
-    constexpr int U = 8;               // loads in flight per lane (4 / 16 / 24 measure the same: the pass runs at 5.1 TB/s)
+    constexpr int U = 8;               // loads in flight per lane (4 / 16 / 24 measure the same)
     for (; z + U <= count; z += U) {
         f2 v[U];
 #pragma unroll
         for (int t = 0; t < U; ++t) v[t] = __builtin_nontemporal_load((const f2*)&q[(size_t)(z + t) * n]);
 #pragma unroll
         for (int t = 0; t < U; ++t) {
-            const int64_t a = pack_key(v[t].x, (uint32_t)(slice0 + z + t)), b = pack_key(v[t].y, (uint32_t)(slice0 + z + t));
-            k0 = a < k0 ? a : k0;
-            k1 = b < k1 ? b : k1;
+            r0.step(v[t].x, (uint32_t)(slice0 + z + t));
+            r1.step(v[t].y, (uint32_t)(slice0 + z + t));
         }
     }
     for (; z < count; ++z) {
         const f2 v = __builtin_nontemporal_load((const f2*)&q[(size_t)z * n]);
-        const int64_t a = pack_key(v.x, (uint32_t)(slice0 + z)), b = pack_key(v.y, (uint32_t)(slice0 + z));
-        k0 = a < k0 ? a : k0;
-        k1 = b < k1 ? b : k1;
+        r0.step(v.x, (uint32_t)(slice0 + z));
+        r1.step(v.y, (uint32_t)(slice0 + z));
     }
-    keys[id] = k0;
-    keys[id + 1] = k1;
+    const int64_t a = r0.key(), c = r1.key();
+    keys[id] = a < k0 ? a : k0;
+    keys[id + 1] = c < k1 ? c : k1;
 }
 
 }  // namespace v4

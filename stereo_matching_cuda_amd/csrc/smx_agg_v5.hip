@@ -1341,6 +1341,11 @@ __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K
     for (int j = 0; j < EPL; ++j) any = any || kp[j];
     if (!any) return;
     typedef float fv __attribute__((ext_vector_type(EPL)));
+    WtaRun run[EPL];                    // (smx_common.h: the winner of this call's slices in the float domain, packed once)
+    auto step = [&](const fv v, unsigned slice) {
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) run[j].step(v[j], slice);
+    };
     int z = 0;
     constexpr int U = 8;
     for (; z + U <= count; z += U) {
@@ -1352,20 +1357,13 @@ __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K
         for (int t = 0; t < U; ++t) v[t] = __builtin_nontemporal_load((const fv*)&q[(size_t)(z + t) * np]);
 #endif
 #pragma unroll
-        for (int t = 0; t < U; ++t)
-#pragma unroll
-            for (int j = 0; j < EPL; ++j) {
-                const int64_t kk = pack_key(v[t][j], (uint32_t)(slice0 + z + t));
-                key[j] = kk < key[j] ? kk : key[j];
-            }
+        for (int t = 0; t < U; ++t) step(v[t], (unsigned)(slice0 + z + t));
     }
-    for (; z < count; ++z) {
-        const fv v = __builtin_nontemporal_load((const fv*)&q[(size_t)z * np]);
+    for (; z < count; ++z) step(__builtin_nontemporal_load((const fv*)&q[(size_t)z * np]), (unsigned)(slice0 + z));
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-            const int64_t kk = pack_key(v[j], (uint32_t)(slice0 + z));
-            key[j] = kk < key[j] ? kk : key[j];
-        }
+    for (int j = 0; j < EPL; ++j) {
+        const int64_t kk = run[j].key();
+        key[j] = kk < key[j] ? kk : key[j];
     }
 #pragma unroll
     for (int j = 0; j < EPL; ++j)

@@ -263,6 +263,15 @@ __attribute__((visibility("default"))) int smx_debug_v5_fix_bytes(int w, int h, 
     return SMX_OK;
 }
 
+// (dev / test hook, not in smx.h: WtaRun, the float-domain winner of a run of ascending slices as the WTA kernels form it)
+__attribute__((visibility("default"))) int smx_debug_wta_run(const float* q, int n, uint32_t slice0, int64_t* key) {
+    SMX_ARG(q && key && n >= 0);
+    WtaRun r;
+    for (int i = 0; i < n; ++i) r.step(q[i], slice0 + (uint32_t)i);
+    *key = r.key();
+    return SMX_OK;
+}
+
 // (dev / test hook, not in smx.h: the comb walker's slot geometry for an image of h rows in K strips -- bands per item, the
 // last stage-2 slot, the period between the starts of two items of a workgroup -- for tools/v5_protocol_sim.py)
 __attribute__((visibility("default"))) int smx_debug_v5_period(int h, int K, int* bands, int* q_last, int* period) {

@@ -107,6 +107,21 @@ __host__ __device__ inline int64_t pack_key(float cost, uint32_t slice) {
     return (int64_t)(((uint64_t)u << 32) | (uint64_t)(0xFFFFFFFFu - slice));
 }
 
+// The winner of a run of ASCENDING slices in the float domain: smallest cost, among equal costs (-0 == +0) the LAST slice, a NaN
+// never -- `take = q <= m` from m = +inf with no slice yet.  That is the order of the packed keys restricted to ascending
+// slices; key() packs the winner once (the identity if nothing was taken), and the caller merges it with the key a pixel already
+// holds by the integer min.  (Packing every candidate costs ten vector instructions per element, a step costs three.)
+struct WtaRun {
+    float m = __builtin_inff();
+    uint32_t z = 0xFFFFFFFFu;
+    __host__ __device__ inline void step(float q, uint32_t slice) {
+        const bool take = q <= m;
+        m = take ? q : m;
+        z = take ? slice : z;
+    }
+    __host__ __device__ inline int64_t key() const { return z == 0xFFFFFFFFu ? KEY_IDENTITY : pack_key(m, z); }
+};
+
 __host__ __device__ inline void unpack_key(int64_t key, float* cost, uint32_t* slice) {
     uint32_t u = (uint32_t)((uint64_t)key >> 32);
     u = (u & 0x80000000u) ? ~(u ^ 0x80000000u) : u;

@@ -179,6 +179,33 @@ def test_comb_walker_descriptor_bound(lib):
     assert fix(8192, 5000, 2) < fix(8192, 5460, 2) < fix(8400, 5460, 2) and fix(8192, 5460, 1) < fix(8192, 5460, 2)
 
 
+def test_wta_run_equals_the_min_of_the_packed_keys(lib):
+    """The WTA kernels pick the winner of a call's slices in the float domain (`take = q <= m`, smx_common.h WtaRun) and pack it
+    once; that must be the integer min of the packed keys of every candidate (pack_key: cost ascending, -0 == +0, among equal
+    costs the larger slice, NaN = the identity) -- dispSelectOnGPU's `best >= q` rule (guidedFilter.cu:403-411)."""
+    so = C.CDLL(_lib.SO_PATH)
+    so.smx_debug_wta_run.restype = C.c_int
+    so.smx_debug_wta_run.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_uint32, C.POINTER(C.c_int64)]
+    so.smx_pack_key.restype, so.smx_pack_key.argtypes = C.c_int64, [C.c_float, C.c_uint32]
+    ident = 0x7FFFFFFFFFFFFFFF
+    rng = np.random.default_rng(11)
+    special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, -np.nan, 1.0, -1.0, 3.4e38, -3.4e38, 1e-45, -1e-45], np.float32)
+    for it in range(400):
+        n = int(rng.integers(0, 20))
+        if it % 3 == 0:
+            q = rng.choice(special, size=n)
+        elif it % 3 == 1:
+            q = rng.choice(np.concatenate([special, rng.integers(-3, 4, size=6).astype(np.float32)]), size=n)
+        else:
+            q = rng.standard_normal(n).astype(np.float32)
+        q = np.ascontiguousarray(q, np.float32)
+        s0 = int(rng.integers(0, 1000))
+        want = min([so.smx_pack_key(float(v), s0 + i) for i, v in enumerate(q)], default=ident)
+        got = C.c_int64()
+        assert so.smx_debug_wta_run(q.ctypes.data_as(C.POINTER(C.c_float)), n, s0, C.byref(got)) == 0
+        assert got.value == want, (q, s0, got.value, want)
+
+
 def test_max_slices_per_launch_knob(lib):
     assert lib.smx_set_max_slices_per_launch(-1) == -1
     assert lib.smx_set_max_slices_per_launch(7) == 0 and lib.smx_set_max_slices_per_launch(0) == 0
