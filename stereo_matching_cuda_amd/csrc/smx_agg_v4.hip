@@ -1315,7 +1315,7 @@ size_t v4_workspace_bytes(int w, int h, int nslices) {
     b += 2 * align_up(L.fg * 4, 256);                               // both image planes (single-view calls too)
     b += align_up(L.plane * 8, 256);                                // (mean_I, 1/(var+eps))
     b += 2 * align_up(L.plane * 4, 256);                            // guidance scratch: integrals of I, I*I
-    const size_t qp5 = (size_t)v5::strips(w) * h * v5::OWS;          // comb-ordered q plane of the comb walker
+    const size_t qp5 = v5::q_plane_floats(w, h);                     // comb-ordered q plane of the comb walker
     b += (size_t)nslices * align_up((L.plane > qp5 ? L.plane : qp5) * 4, 256);   // q
     b += align_up((size_t)v5::strips(w) * v5::bands(h) * v5::CLP * 100, 256) + 512;   // comb-ordered guidance planes (80 + 20 B per lane and band)
     const size_t hand5 = v5::sv_hand_floats(h);                    // the comb walker's records (smx_agg_v5.hip)
@@ -1464,7 +1464,7 @@ int aggregate_v4(const smx_params* p, int nviews, const uint8_t* const* d_guide,
     // per slice-view: q plane (unless the caller's volume is written directly) + records + flags
     const bool own_q = !(d_agg && d_agg[0]);
     // (the comb walker's own q planes are comb-ordered: K * OWS >= w columns per row)
-    const size_t qplane = use_v5 && own_q ? (size_t)L.K * h * v5::OWS : L.plane;
+    const size_t qplane = use_v5 && own_q ? v5::q_plane_floats(w, h) : L.plane;
     const size_t per_sv = (own_q ? align_up(qplane * 4, 256) : 0) + sv_hand_c * 4 +
                           (size_t)K_c * sizeof(unsigned);
     size_t fit = avail > 8 * 256 + V4_CTRL_BYTES ? (avail - 8 * 256 - V4_CTRL_BYTES) / (per_sv * nviews) : 0;

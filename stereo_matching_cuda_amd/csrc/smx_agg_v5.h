@@ -28,8 +28,9 @@ struct Args {
     // [k][y][cl], so that a wave's guidance load is one contiguous run instead of 16 clusters of 4 columns
     unsigned o_g1p[2];    // float4 [K][5 NI][CLP]: (mean_I, 1/(var_I + eps)) of the a/b rows 2 P - 9, 2 P - 8 (row pair P on the band grid) at the a/b column OWS k - 10 + 19 il + rho
     unsigned o_i2p[2];    // u32x4 [K][NI][CLP] + u32 [K][NI][CLP] behind it: image values (fp16 pairs) of the ten q rows of band ib at the q column OWS k - 19 + 19 il + rho
-    // out, per view: qperm != 0: comb-ordered scratch [slice][K][h][OWS], column OWS k + 19 (il-1) + rho at
-    // [(L-1) rho + il - 1] (a wave stores one contiguous run; read back by k_v5_wta); else the caller's [slice][h][w]
+    // out, per view: qperm != 0: comb-ordered scratch [slice][K][ceil(h/2)][OWS][2]: the rows 2 yp, 2 yp + 1 of column
+    // OWS k + 19 (il-1) + rho side by side at [(L-1) rho + il - 1] (a wave stores ONE contiguous run of 8-byte units per row
+    // pair -- round 5: half the store instructions of a row at a time; read back by k_v5_wta); else the caller's [slice][h][w]
     // materialised cost volumes (src_cost != 0): slice s of view v at cost[v] + s * cost_plane, [h][w] each (the reference's
     // calling convention, guidedFilter.cu:198); else the costs are built from the image planes
     const float* cost[2];
@@ -53,6 +54,7 @@ struct Args {
 };
 
 inline int strips(int w) { return (w + OWS - 1) / OWS; }
+inline size_t q_plane_floats(int w, int h) { return (size_t)strips(w) * ((h + 1) / 2) * 2 * OWS; }   // comb-ordered q scratch per slice: row pairs
 inline int bands(int h) { return (h + 2 * 9 + BH - 1) / BH + 2; }     // the q rows of iteration i end at 10 i - 28
 inline int records(int h) { return bands(h) + 2; }                   // hand-off records per (strip boundary, slice-view)
 // An item occupies its roles for fewer slots than it has: the cost wave for local slots -2 .. s1_last - 2, stage 1 for

@@ -230,8 +230,11 @@ __device__ __forceinline__ void tile_wr(float* p, f2 v) { p[0] = v.x; p[P1] = v.
 // FASTK = 1: the FAST mode (smx_set_agg_path(4)): window means by multiplication with the rounded reciprocal of the area
 // instead of the correctly rounded division, no exactness vote -- the same sums in the same order, at most an ulp or two away
 // per mean; NOT bit-exact, never the default
-template <int FASTK>
+// QP = 1: q goes to the library's own comb-ordered scratch (Args::qperm; the product default), 0: into the caller's [slice][h][w]
+// volume -- a template parameter because a run-time choice between the two store forms inside the row pairs cost 1.4 % of a pair.
+template <int FASTK, int QP>
 __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
+    constexpr bool QPERM = QP != 0;
     __shared__ __attribute__((aligned(16))) float tile1[NT1][TILE_F];
     __shared__ __attribute__((aligned(16))) float tile2s[NT2][TILE_F];
     __shared__ float cin1s[2][BH][2];                               // stage-1 row carries of the band the next scan pass takes (by pass parity)
@@ -349,7 +352,8 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             pairB = (slice & 1) != 0;
             r_qp = mk_rsrc(A.q[view] + (size_t)(slice > 0 ? slice - 1 : 0) * A.q_plane, A.q_plane * 4);
 #endif
-            q_pitch = A.qperm ? OWS * 4 : (int)w4; q_row0 = A.qperm ? k * h * (OWS * 4) : 0;
+            // (qperm: q_pitch is the pitch of a row PAIR, the rows of a pair lie side by side -- smx_agg_v5.h)
+            q_pitch = QPERM ? OWS * 8 : (int)w4; q_row0 = QPERM ? k * ((h + 1) / 2) * (OWS * 8) : 0;
             xedge = base1 < 0 || base1 + SW > w;
         };
         // the tile-2 buffer the comb rows of stage 1 write / the next scan pass takes for stage 2 and the hand-in fills,
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 // comb-ordered scratch: 8 rho + (i - 1): the eight outputs of a comb are 32 contiguous bytes.  The LAST strip
                 // is stored in column order instead (19 (i - 1) + rho = the local column), so that what lies outside the image is
                 // one contiguous tail of its rows that the WTA pass never reads.
-                vo = !col_ok ? OOB : (A.qperm ? (unsigned)(k + 1 < K ? (L - 1) * comb_rho() + il - 1 : HW * (il - 1) + comb_rho()) * 4u : (unsigned)xo * 4u);
+                vo = !col_ok ? OOB : (QPERM ? (unsigned)(k + 1 < K ? (L - 1) * comb_rho() + il - 1 : HW * (il - 1) + comb_rho()) * 8u : (unsigned)xo * 4u);
             }
             ca_i = (f2){rcp_i, (float)(HW * xw)};
             okmask = __builtin_amdgcn_ballot_w64(col_ok);
@@ -894,8 +898,14 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             }
 #endif
             if (!(WHATIF & 16)) {
-                if (va) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qva), r_q, (int)vo, q_row0 + yq * q_pitch, AUX_NT);
-                if (vb) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qvb), r_q, (int)vo, q_row0 + (yq + 1) * q_pitch, AUX_NT);
+                if constexpr (QPERM) {
+                    // own scratch: the two rows of the pair as ONE 8-byte store (yq is even; a row behind an image of odd height
+                    // lands in the padding row of the last pair)
+                    if (va) __builtin_amdgcn_raw_buffer_store_b64((u2){__builtin_bit_cast(unsigned, qva), __builtin_bit_cast(unsigned, qvb)}, r_q, (int)vo, q_row0 + (yq >> 1) * q_pitch, AUX_NT);
+                } else {
+                    if (va) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qva), r_q, (int)vo, q_row0 + yq * q_pitch, AUX_NT);
+                    if (vb) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, qvb), r_q, (int)vo, q_row0 + (yq + 1) * q_pitch, AUX_NT);
+                }
             }
             if constexpr (BORDER) rcb = rcn;
             __builtin_amdgcn_sched_barrier(0);
@@ -1046,7 +1056,10 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                         if (pairB) {
 #pragma unroll
                             for (int t = 0; t < BH; ++t)
-                                qo[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_qp, (int)vo, q_row0 + min(max(yq0 + t, 0), h - 1) * q_pitch, AUX_NT));
+                            {
+                                const int yc = min(max(yq0 + t, 0), h - 1);
+                                qo[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_qp, (int)vo, q_row0 + (QPERM ? (yc >> 1) * q_pitch + (yc & 1) * 4 : yc * q_pitch), AUX_NT));
+                            }
                         }
                     }
 #endif
@@ -1298,9 +1311,9 @@ __global__ __launch_bounds__(CLP) void k_v5_perm(PermArgs pa, int w, int h, int 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// WTA over the chunk's comb-ordered q planes [slice][K][h][OWS] (dispSelectOnGPU guidedFilter.cu:403-411 in
-// packed-key form): one lane per element, coalesced nt loads, 8 in flight; the keys stay [h][w] -- the lane finds
-// its pixel once per call.  grid (ceil(K h OWS / 256), nviews)
+// WTA over the chunk's comb-ordered q planes [slice][K][ceil(h/2)][OWS][2] (dispSelectOnGPU guidedFilter.cu:403-411):
+// four elements per lane (two columns x the two rows of a pair), coalesced nt loads, 8 in flight; the keys stay [h][w] --
+// the lane finds its pixels once per call.  grid (ceil(plane / 1024), nviews)
 // ---------------------------------------------------------------------------------------------------------------
 struct Wta5Args {
     const float* q[2];
@@ -1310,10 +1323,11 @@ struct Wta5Args {
 };
 // Four elements per lane, 16-byte loads: a strip row is OWS = 152 floats, so a plane is a whole number of quads, and the
 // planes are carved 256-byte aligned (aggregate_v4)
-static_assert(OWS % 4 == 0, "quads do not straddle strip rows");
+static_assert((2 * OWS) % 4 == 0, "quads (two columns x the two rows of a pair) do not straddle pair rows");
 __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K, int count, int slice0) {
     constexpr int EPL = 4;
-    const size_t np = (size_t)K * h * OWS;
+    const int hp = (h + 1) / 2;                                 // row pairs: [K][hp][OWS][2] (smx_agg_v5.h)
+    const size_t np = (size_t)K * hp * (2 * OWS);
 #ifdef SMX_WTA_REV       // (A/B: the planes back to front -- the strips the walker wrote last first)
     const size_t e0 = ((size_t)(gridDim.x - 1 - blockIdx.x) * 256 + threadIdx.x) * EPL;
 #else
@@ -1328,11 +1342,11 @@ __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K
 #pragma unroll
     for (int j = 0; j < EPL; ++j) {
         const size_t e = e0 + j;
-        const int row = (int)(e / OWS), p = (int)(e - (size_t)row * OWS);   // row = k h + y
-        const int k = row / h, y = row - k * h;
+        const int prow = (int)(e / (2 * OWS)), rem = (int)(e - (size_t)prow * (2 * OWS));   // prow = k hp + yp
+        const int p = rem >> 1, k = prow / hp, y = 2 * (prow - k * hp) + (rem & 1);
         const int rho = p / (L - 1), i1 = p - (L - 1) * rho;
         const int x = OWS * k + (k + 1 < K ? HW * i1 + rho : p);        // (the last strip is in column order)
-        kp[j] = e < np && x < w ? keys + (size_t)y * w + x : nullptr;
+        kp[j] = e < np && x < w && y < h ? keys + (size_t)y * w + x : nullptr;
         key[j] = kp[j] && !wa.fresh ? *kp[j] : KEY_IDENTITY;
     }
     // nothing of this lane lies in the image (the tail of a row of the last strip): no load at all
@@ -1395,7 +1409,7 @@ int v5_wta_launch(int nviews, const float* const* q, int64_t* const* keys, int w
     wa.fresh = fresh ? 1 : 0;
     for (int v = 0; v < 2; ++v) { wa.q[v] = q[v < nviews ? v : 0]; wa.keys[v] = keys[v < nviews ? v : 0]; }
     const int K = v5::strips(w);
-    const size_t np = (size_t)K * h * v5::OWS;
+    const size_t np = v5::q_plane_floats(w, h);
     for (int v = 0; v < nviews; ++v)
         if (((uintptr_t)wa.q[v] & 15) != 0) return fail(SMX_E_ARG, "v5_wta_launch: q scratch of view %d is not 16-byte aligned", v);
     hipLaunchKernelGGL(v5::k_v5_wta, dim3((unsigned)((np / 4 + 255) / 256), (unsigned)nviews), dim3(256), 0, st, wa, w, h, K,
@@ -1436,8 +1450,10 @@ int v5_launch(const v5::Args& a, hipStream_t st) {
     if (env_per_cu >= 1 && env_per_cu <= v5::WG_PER_CU) per_cu = env_per_cu;
     const int slots = per_cu * ncu;
     const int grid = a.nitems < slots ? a.nitems : slots;
-    if (a.fast) hipLaunchKernelGGL((v5::k_v5_walk<1>), dim3((unsigned)grid), dim3(v5::NT), 0, st, a);
-    else hipLaunchKernelGGL((v5::k_v5_walk<0>), dim3((unsigned)grid), dim3(v5::NT), 0, st, a);
+    if (a.fast && a.qperm) hipLaunchKernelGGL((v5::k_v5_walk<1, 1>), dim3((unsigned)grid), dim3(v5::NT), 0, st, a);
+    else if (a.fast) hipLaunchKernelGGL((v5::k_v5_walk<1, 0>), dim3((unsigned)grid), dim3(v5::NT), 0, st, a);
+    else if (a.qperm) hipLaunchKernelGGL((v5::k_v5_walk<0, 1>), dim3((unsigned)grid), dim3(v5::NT), 0, st, a);
+    else hipLaunchKernelGGL((v5::k_v5_walk<0, 0>), dim3((unsigned)grid), dim3(v5::NT), 0, st, a);
     SMX_HIP(hipGetLastError());
     return SMX_OK;
 }
@@ -1445,9 +1461,9 @@ int v5_launch(const v5::Args& a, hipStream_t st) {
 // Residency of the walker as the runtime sees it (dev tool: tools/v5_quick.py --occupancy)
 extern "C" __attribute__((visibility("default"))) int smx_debug_v5_occupancy(int* blocks_per_cu, int* vgprs, int* lds_bytes) {
     int nb = 0;
-    SMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)v5::k_v5_walk<0>, v5::NT, 0));
+    SMX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)v5::k_v5_walk<0, 1>, v5::NT, 0));
     hipFuncAttributes fa;
-    SMX_HIP(hipFuncGetAttributes(&fa, (const void*)v5::k_v5_walk<0>));
+    SMX_HIP(hipFuncGetAttributes(&fa, (const void*)v5::k_v5_walk<0, 1>));
     if (blocks_per_cu) *blocks_per_cu = nb;
     if (vgprs) *vgprs = fa.numRegs;
     if (lds_bytes) *lds_bytes = (int)fa.sharedSizeBytes;

@@ -63,7 +63,7 @@ def main(dst=None):
                               stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         asm = open(os.path.join(td, "smx_agg_v5-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
     # the exact kernel (template argument 0); the FAST instantiation comes first in the file
-    first = next(i for i, l in enumerate(asm) if l.startswith("_ZN3smx2v59k_v5_walkILi0"))
+    first = next(i for i, l in enumerate(asm) if l.startswith("_ZN3smx2v59k_v5_walkILi0ELi1E"))
     asm = asm[first:]
     out = []
     cols = ["valu", "valu_pk", "valu_dpp", "valu_lane", "salu", "s_nop", "s_waitcnt", "lds", "vmem"]
