@@ -144,7 +144,7 @@ constexpr int WMAP = SMX_V5_WMAP;
 #ifndef SMX_V5_TOUCH
 #define SMX_V5_TOUCH 0      // (A/B: load-to-LDS touches of the next band's cost lines: slower, 0.84 against 0.78 ms per KITTI pair)
 #endif
-constexpr int S2_KEEP = SMX_V5_S2_KEEP;     // vector-memory operations a stage-2 wave issues behind its record store in an interior slot
+constexpr int S2_KEEP = SMX_V5_S2_KEEP;     // vector-memory operations a stage-2 wave issues behind its record store in an interior slot (ten q rows + two loads; five less with row-pair stores)
 constexpr int PRIO_COST = SMX_V5_PRIO_COST, PRIO_S1 = SMX_V5_PRIO_S1, PRIO_S2HEAD = SMX_V5_PRIO_S2HEAD, PRIO_SCAN = SMX_V5_PRIO_SCAN;
 
 #if (SMX_V5_WHATIF & 16384)
@@ -1076,9 +1076,10 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 issue_guid(sl, BH * (sl - 1) - 2 * R);
                 // the record stored above is complete in memory before the barrier behind which it is published
                 // (vector-memory operations of a wave complete in issue order: what was issued behind the record store -- the
-                // ten q rows of an interior band and the two guidance loads -- may stay in flight; -DSMX_V5_S2_KEEP=0: the
-                // full drain of round 4; the item's last slot drains everything: FLAG_DONE follows)
-                if (S2_KEEP > 0 && s2_interior) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(S2_KEEP) : "memory"); else
+                // q stores of an interior band, ten rows or five row pairs, and the two guidance loads -- may stay in flight;
+                // -DSMX_V5_S2_KEEP=0: the full drain of round 4; the item's last slot drains everything: FLAG_DONE follows)
+                constexpr int KEEP = S2_KEEP > 0 ? (QPERM ? S2_KEEP - BH / 2 : S2_KEEP) : 0;
+                if (KEEP > 0 && s2_interior) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KEEP) : "memory"); else
                 drain_vmem();
             }
         };

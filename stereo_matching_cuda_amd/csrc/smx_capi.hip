@@ -138,7 +138,7 @@ void smx_default_params(smx_params* p) {
 
 const char* smx_last_error(void) { return g_err.c_str(); }
 
-const char* smx_version(void) { return "smx-hip gfx950 0.8 (pipelined comb walker: items pipelined across tickets, border bands on the row-pair path, guidance ring, cost volumes on the comb walker; two 512-thread workgroups per CU)"; }
+const char* smx_version(void) { return "smx-hip gfx950 0.9 (comb walker: items pipelined across tickets, q scratch in row pairs, cost volumes on the comb walker; WTA winner in the float domain; guidance in three launches; two 512-thread workgroups per CU)"; }
 
 int smx_device_count(void) {
     int n = 0;
