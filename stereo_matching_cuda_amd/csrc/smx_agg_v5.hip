@@ -1322,8 +1322,8 @@ struct Wta5Args {
     const unsigned* skip_if;      // != NULL: the pass does nothing if this word is nonzero (the comb walker's planes do not count)
     int fresh;                    // != 0: the keys hold nothing yet (no smx_dev_init_keys ran): start from the identity, do not load them
 };
-// Four elements per lane, 16-byte loads: a strip row is OWS = 152 floats, so a plane is a whole number of quads, and the
-// planes are carved 256-byte aligned (aggregate_v4)
+// Four elements per lane, 16-byte loads: a row pair of a strip is 2 OWS = 304 floats, so a plane is a whole number of quads
+// and every plane starts 64-byte aligned (q_plane_floats is a multiple of 304; the scratch is carved 256-byte aligned)
 static_assert((2 * OWS) % 4 == 0, "quads (two columns x the two rows of a pair) do not straddle pair rows");
 __global__ __launch_bounds__(256) void k_v5_wta(Wta5Args wa, int w, int h, int K, int count, int slice0) {
     constexpr int EPL = 4;
