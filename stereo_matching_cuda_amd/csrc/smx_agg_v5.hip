@@ -645,8 +645,13 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
             const int ibc = __builtin_amdgcn_readfirstlane(min(max(ib, 0), NI - 1));
             if constexpr (ST2) {
                 // (yq0 = 10 (ib - 1) - 18 at every call site: the band grid of the planes)
+#ifdef SMX_V5_GI_B32     // (A/B: five 4-byte loads straight into their registers instead of a 16-byte load that needs an aligned quad)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) gI[c] = ldu(r_fix, vg * 4u, o_i2p + ibc * (CLP * 16) + 4 * c);
+#else
                 const u4 a = __builtin_bit_cast(u4, __builtin_amdgcn_raw_buffer_load_b128(r_fix, (int)(vg * 4u), o_i2p + ibc * (CLP * 16), 0));
                 gI[0] = a.x; gI[1] = a.y; gI[2] = a.z; gI[3] = a.w;
+#endif
                 gI[4] = ldu(r_fix, vg, o_i2b + ibc * (CLP * 4));
             }
         };
@@ -1078,7 +1083,11 @@ __global__ __launch_bounds__(NT, WPE) void k_v5_walk(Args A) {
                 // (vector-memory operations of a wave complete in issue order: what was issued behind the record store -- the
                 // q stores of an interior band, ten rows or five row pairs, and the two guidance loads -- may stay in flight;
                 // -DSMX_V5_S2_KEEP=0: the full drain of round 4; the item's last slot drains everything: FLAG_DONE follows)
+#ifdef SMX_V5_GI_B32
+                constexpr int KEEP = S2_KEEP > 0 ? (QPERM ? S2_KEEP - BH / 2 : S2_KEEP) + 3 : 0;
+#else
                 constexpr int KEEP = S2_KEEP > 0 ? (QPERM ? S2_KEEP - BH / 2 : S2_KEEP) : 0;
+#endif
                 if (KEEP > 0 && s2_interior) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KEEP) : "memory"); else
                 drain_vmem();
             }
